@@ -1,0 +1,167 @@
+/* libscnattn -- C ABI of the MI355X (gfx950) SCN+Attention training path.
+ *
+ * The reference (rayandrew/indonesian-image-captioning) has no FFI layer: its hot path is eager
+ * PyTorch.  This header is the boundary that sits UNDER the reference's nn.Module API
+ * (SURVEY.md 8b); each entry point names the reference code it replaces (paths relative to the
+ * reference checkout).  The Python binding a maintainer adds is in INTEGRATION.md (ctypes).
+ *
+ * Conventions
+ *   - plain pointers + sizes, fp32 row-major device memory, int64 token ids, no torch types;
+ *   - every call is asynchronous on the hipStream_t passed as `void* stream` (0 = null stream);
+ *   - the library allocates nothing: callers pass workspaces sized by scnattn_seq_workspace();
+ *   - return 0 on success, <0 for invalid arguments, >0 = hipError_t; message (thread-local) from
+ *     scnattn_last_error(); no exceptions or aborts cross this boundary; entry points are
+ *     re-entrant (autograd calls backward from its own thread).
+ */
+#ifndef SCNATTN_H
+#define SCNATTN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCNATTN_VERSION 100 /* 0.1.0 */
+
+int scnattn_version(void);
+const char* scnattn_last_error(void);
+/* Tuning knobs (e.g. "ksplit_scale"); returns -1 for an unknown name. */
+int scnattn_set_option(const char* name, int value);
+
+/* ---- dimensions of one decoder (models/decoders/attention_scn.py:28-56, pure_scn.py:26-48) ------ */
+typedef struct {
+    int B;       /* batch rows                                                         */
+    int P;       /* pixels per image (14*14)                                           */
+    int E;       /* encoder_dim                                                        */
+    int A;       /* attention_dim   (ignored when has_att == 0)                        */
+    int D;       /* decoder_dim == SCNCell.hidden_size                                 */
+    int F;       /* factored_dim                                                       */
+    int M;       /* embed_dim                                                          */
+    int S;       /* semantic_dim (tags)                                                */
+    int V;       /* vocab_size                                                         */
+    int T;       /* decode steps = max(decode_lengths)                                 */
+    int L;       /* width of the caption tensor (>= T)                                 */
+    int has_att; /* 1: AttentionSCN (SCNCell input = M+E), 0: PureSCN (input = M)      */
+} scnattn_dims;
+
+/* Parameter pointers, named after the reference's state_dict keys.  The same struct (with
+ * writable memory behind it) receives the gradients in scnattn_seq_bwd. */
+typedef struct {
+    float* attention_encoder_att_weight; /* [A,E]   models/attention.py:18 */
+    float* attention_encoder_att_bias;   /* [A]                            */
+    float* attention_decoder_att_weight; /* [A,D]   models/attention.py:20 */
+    float* attention_decoder_att_bias;   /* [A]                            */
+    float* attention_full_att_weight;    /* [1,A]   models/attention.py:22 */
+    float* attention_full_att_bias;      /* [1]                            */
+    float* embedding_weight;             /* [V,M]   attention_scn.py:43    */
+    float* decode_step_weight_ia;        /* [I,4F]  models/scn_cell.py:29  */
+    float* decode_step_weight_ib;        /* [S,4F]                         */
+    float* decode_step_weight_ic;        /* [D,4F]                         */
+    float* decode_step_weight_ha;        /* [D,4F]                         */
+    float* decode_step_weight_hb;        /* [S,4F]                         */
+    float* decode_step_weight_hc;        /* [D,4F]                         */
+    float* decode_step_bias_ih;          /* [4D]                           */
+    float* decode_step_bias_hh;          /* [4D]                           */
+    float* init_h_weight;                /* [D,E]   attention_scn.py:48    */
+    float* init_h_bias;                  /* [D]                            */
+    float* init_c_weight;                /* [D,E]                          */
+    float* init_c_bias;                  /* [D]                            */
+    float* f_beta_weight;                /* [E,D]   attention_scn.py:52    */
+    float* f_beta_bias;                  /* [E]                            */
+    float* fc_weight;                    /* [V,D]   attention_scn.py:55    */
+    float* fc_bias;                      /* [V]                            */
+} scnattn_params;
+
+/* Bytes of the two workspaces of the sequence drivers.  `saved` carries forward state to the
+ * backward pass; `scratch` is free after each call.  Both must be zero-filled by the caller before
+ * scnattn_seq_fwd (saved) / each call (scratch). */
+int scnattn_seq_workspace(const scnattn_dims* d, size_t* saved_bytes, size_t* scratch_bytes);
+
+/* Teacher-forced decoder forward over all T steps: replaces the loop of
+ * models/decoders/attention_scn.py:124-156 (pure_scn.py:114-138 when has_att == 0), i.e. per step
+ * Attention.forward (models/attention.py:35-44), the f_beta gate, SCNCell.forward/recurrent_step
+ * (models/scn_cell.py:62-154), dropout and fc.
+ *   enc     [B,P,E]  encoder output, rows already permuted by sort_ind
+ *   tags    [B,S]    semantic input, NOT permuted (reference quirk, attention_scn.py:152)
+ *   caps    [B,L]    int64 sorted captions;  dl_dev [B] int32 decode lengths (device)
+ *   bt_host [T]      host array: active rows at step t (non-increasing)
+ *   drop_mask [B,T,D] pre-scaled dropout mask or NULL
+ *   preds   [B,T,V]  out (fully written; rows past a caption's length are 0)
+ *   alphas  [B,T,P]  out, must be zero-filled by the caller (NULL when has_att == 0) */
+int scnattn_seq_fwd(void* stream, const scnattn_dims* d, const scnattn_params* w, const float* enc,
+                    const float* tags, const int64_t* caps, const int32_t* dl_dev, const int32_t* bt_host,
+                    const float* drop_mask, float* saved, float* scratch, float* preds, float* alphas);
+
+/* Gradient of scnattn_seq_fwd (what autograd derives for the reference's loop).  `g` receives
+ * d loss / d parameter (fields may be NULL to skip; embedding_weight must be zero-filled: rows
+ * are accumulated).  denc [B,P,E] and dtags [B,S] may be NULL. */
+int scnattn_seq_bwd(void* stream, const scnattn_dims* d, const scnattn_params* w, const float* enc,
+                    const float* tags, const int64_t* caps, const int32_t* dl_dev, const int32_t* bt_host,
+                    const float* drop_mask, const float* saved, float* scratch, const float* dpreds,
+                    const float* dalphas, const scnattn_params* g, float* denc, float* dtags);
+
+/* ---- primitives (each = one kernel launch); used by the stand-alone modules and the tests ------- */
+/* C = alpha*op(A).op(B) + beta*C + bias[n]; rows with rowmask[m]==0 written as 0.  Replaces the
+ * aten::mm / addmm calls behind nn.Linear and `@` on the path. */
+int scnattn_sgemm(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A,
+                  long lda, const float* B, long ldb, float beta, float* C, long ldc, const float* bias,
+                  const float* rowmask, int batch, long strideA, long strideB, long strideC);
+/* Y[s][g][r][n] = sum_{k in slice s} X[r][g*xg+k] * W[g*wg + k*ldw + n]; ksplit<=0 picks one.
+ * Returns the ksplit used through *ksplit_out. */
+int scnattn_skinny_gemm(void* stream, int rows, int N, int K, int groups, const float* X, long ldx, long xg,
+                        const float* W, long ldw, long wg, float* Y, long ldy, long yg, long yslab,
+                        int ksplit, int* ksplit_out);
+/* models/attention.py:37-39 */
+int scnattn_attn_scores(void* stream, int rows, int P, int A, const float* att1, const float* att2, int nslab,
+                        long slab_stride, long att2_ld, const float* dec_bias, const float* w, const float* b0,
+                        float* e, float* att2_out);
+/* models/attention.py:40-42 (+ gate of attention_scn.py:147-148 when gpre != NULL) */
+int scnattn_attn_context(void* stream, int rows, int P, int E, const float* enc, const float* e,
+                         const float* gpre, int nslab, long slab_stride, long gpre_ld, const float* gate_bias,
+                         float* alpha_out, long alpha_ld, float* alpha_save, float* awe, float* gate, float* z);
+int scnattn_mean_pixels(void* stream, int rows, int P, int E, const float* enc, float* out);
+int scnattn_attn_dalpha(void* stream, int rows, int P, int E, const float* enc, const float* dawe,
+                        const float* dalpha_in, long dalpha_in_ld, float* dalpha);
+int scnattn_attn_softmax_bwd(void* stream, int rows, int P, int A, const float* att1, const float* att2,
+                             const float* w, const float* alpha, const float* dalpha, float* de, float* datt2,
+                             long datt2_ld);
+int scnattn_attn_datt1_post_blocks(int B, int P);
+int scnattn_attn_datt1_post(void* stream, int B, int P, int A, int T, const int32_t* dl, const float* att1,
+                            const float* att2_all, const float* de_all, const float* w, float* datt1,
+                            float* dwpart);
+/* models/scn_cell.py:73-91 / 134-144 element-wise parts */
+int scnattn_scn_mix_fwd(void* stream, int rows, int F4, const float* pz, int pz_nslab, long pz_stride, long pz_ld,
+                        const float* ex, const float* ph, int ph_nslab, long ph_stride, long ph_ld,
+                        const float* qx, const float* qh, float* pa, float* phs, float* xcat);
+/* models/scn_cell.py:146-152 */
+int scnattn_lstm_fwd(void* stream, int rows, int H, const float* r, int nslab, long slab_stride, long r_ld,
+                     long r_gate_stride, const float* bih, const float* bhh, const float* c_prev, float* gates,
+                     float* c_new, float* h_new, float* tanhc);
+int scnattn_lstm_bwd(void* stream, int rows, int rows_next, int H, const float* dh_fc, const float* dh_next,
+                     int nslab, long slab_stride, long dh_ld, float* dc, const float* gates, const float* c_prev,
+                     const float* tanhc, float* dr);
+int scnattn_scn_mix_bwd(void* stream, int rows, int F4, const float* dxcat, int nslab, long slab_stride, long dx_ld,
+                        long dx_gate_stride, const float* qx, const float* qh, const float* pa, const float* phs,
+                        float* dpx, float* dph, long dph_ld, float* dqx_acc, float* dqh_acc);
+int scnattn_gate_bwd(void* stream, int rows, int E, const float* dz, int nslab, long slab_stride, long dz_ld,
+                     const float* awe, const float* gate, float* dawe, float* dgpre, long dgpre_ld);
+/* helpers */
+int scnattn_transpose2d(void* stream, int R, int C, const float* in, long ldi, float* out, long ldo);
+int scnattn_colsum(void* stream, int R, int N, const float* X, long ld, float* out, float beta);
+int scnattn_mul_bcast(void* stream, int T, int B, int N, const float* x, const float* q, float* out);
+/* models/encoders/caption.py:41-43: AdaptiveAvgPool2d((Ho,Wo)) + permute(0,2,3,1); x given by strides */
+int scnattn_pool_permute_fwd(void* stream, int B, int C, int Hin, int Win, int Ho, int Wo, const float* x,
+                             long sxb, long sxc, long sxh, long sxw, float* y);
+int scnattn_pool_permute_bwd(void* stream, int B, int C, int Hin, int Win, int Ho, int Wo, const float* dy,
+                             float* dx, long sxb, long sxc, long sxh, long sxw);
+/* utils/optimizer.py:1-11 (element-wise clamp) fused with torch.optim.Adam's update
+ * (trains/attention_scn.py:244-252); g is first scaled by gscale (1/world for data parallel). */
+int scnattn_clamp_adam(void* stream, long n, float* p, const float* g, float* m, float* v, double lr,
+                       double beta1, double beta2, double eps, int step, double clip, double gscale);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCNATTN_H */

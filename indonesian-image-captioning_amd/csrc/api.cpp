@@ -1,0 +1,181 @@
+// extern "C" surface of libscnattn (declared in include/scnattn.h).
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include "../../include/scnattn.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace scn {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* last_error() { return g_err; }
+
+extern int g_ksplit_scale;
+int seq_workspace(const scnattn_dims* d, size_t* saved_bytes, size_t* scratch_bytes);
+int seq_fwd(hipStream_t st, const scnattn_dims* d, const scnattn_params* w, const float* enc, const float* tags,
+            const int64_t* caps, const int32_t* dl_dev, const int32_t* bt, const float* drop_mask, float* saved,
+            float* scratch, float* preds, float* alphas);
+int seq_bwd(hipStream_t st, const scnattn_dims* d, const scnattn_params* w, const float* enc, const float* tags,
+            const int64_t* caps, const int32_t* dl_dev, const int32_t* bt, const float* drop_mask, const float* saved,
+            float* scratch, const float* dpreds, const float* dalphas, const scnattn_params* g, float* denc,
+            float* dtags);
+
+}  // namespace scn
+
+using namespace scn;
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" {
+
+int scnattn_version(void) { return SCNATTN_VERSION; }
+const char* scnattn_last_error(void) { return last_error(); }
+
+int scnattn_set_option(const char* name, int value) {
+    if (name && std::strcmp(name, "ksplit") == 0) {
+        g_ksplit_scale = value;
+        return 0;
+    }
+    set_error("scnattn_set_option: unknown option '%s'", name ? name : "(null)");
+    return -1;
+}
+
+int scnattn_seq_workspace(const scnattn_dims* d, size_t* saved_bytes, size_t* scratch_bytes) {
+    return seq_workspace(d, saved_bytes, scratch_bytes);
+}
+
+int scnattn_seq_fwd(void* stream, const scnattn_dims* d, const scnattn_params* w, const float* enc,
+                    const float* tags, const int64_t* caps, const int32_t* dl_dev, const int32_t* bt_host,
+                    const float* drop_mask, float* saved, float* scratch, float* preds, float* alphas) {
+    return seq_fwd(ST(stream), d, w, enc, tags, caps, dl_dev, bt_host, drop_mask, saved, scratch, preds, alphas);
+}
+
+int scnattn_seq_bwd(void* stream, const scnattn_dims* d, const scnattn_params* w, const float* enc,
+                    const float* tags, const int64_t* caps, const int32_t* dl_dev, const int32_t* bt_host,
+                    const float* drop_mask, const float* saved, float* scratch, const float* dpreds,
+                    const float* dalphas, const scnattn_params* g, float* denc, float* dtags) {
+    return seq_bwd(ST(stream), d, w, enc, tags, caps, dl_dev, bt_host, drop_mask, saved, scratch, dpreds, dalphas, g,
+                   denc, dtags);
+}
+
+int scnattn_sgemm(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A,
+                  long lda, const float* B, long ldb, float beta, float* C, long ldc, const float* bias,
+                  const float* rowmask, int batch, long strideA, long strideB, long strideC) {
+    return sgemm(ST(stream), transA != 0, transB != 0, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, rowmask,
+                 batch < 1 ? 1 : batch, strideA, strideB, strideC);
+}
+
+int scnattn_skinny_gemm(void* stream, int rows, int N, int K, int groups, const float* X, long ldx, long xg,
+                        const float* W, long ldw, long wg, float* Y, long ldy, long yg, long yslab,
+                        int ksplit, int* ksplit_out) {
+    if (ksplit <= 0) ksplit = skinny_pick_ksplit(rows, N, K, groups);
+    if (ksplit_out) *ksplit_out = ksplit;
+    return skinny_gemm(ST(stream), rows, N, K, groups, X, ldx, xg, W, ldw, wg, Y, ldy, yg, yslab, ksplit);
+}
+
+int scnattn_attn_scores(void* stream, int rows, int P, int A, const float* att1, const float* att2, int nslab,
+                        long slab_stride, long att2_ld, const float* dec_bias, const float* w, const float* b0,
+                        float* e, float* att2_out) {
+    return attn_scores(ST(stream), rows, P, A, att1, Slabs{att2, nslab, slab_stride, att2_ld}, dec_bias, w, b0, e,
+                       att2_out);
+}
+
+int scnattn_attn_context(void* stream, int rows, int P, int E, const float* enc, const float* e,
+                         const float* gpre, int nslab, long slab_stride, long gpre_ld, const float* gate_bias,
+                         float* alpha_out, long alpha_ld, float* alpha_save, float* awe, float* gate, float* z) {
+    return attn_context(ST(stream), rows, P, E, enc, e, Slabs{gpre, nslab, slab_stride, gpre_ld}, gate_bias,
+                        alpha_out, alpha_ld, alpha_save, awe, gate, z);
+}
+
+int scnattn_mean_pixels(void* stream, int rows, int P, int E, const float* enc, float* out) {
+    return mean_pixels(ST(stream), rows, P, E, enc, out);
+}
+
+int scnattn_attn_dalpha(void* stream, int rows, int P, int E, const float* enc, const float* dawe,
+                        const float* dalpha_in, long dalpha_in_ld, float* dalpha) {
+    return attn_dalpha(ST(stream), rows, P, E, enc, dawe, dalpha_in, dalpha_in_ld, dalpha);
+}
+
+int scnattn_attn_softmax_bwd(void* stream, int rows, int P, int A, const float* att1, const float* att2,
+                             const float* w, const float* alpha, const float* dalpha, float* de, float* datt2,
+                             long datt2_ld) {
+    return attn_softmax_bwd(ST(stream), rows, P, A, att1, att2, w, alpha, dalpha, de, datt2, datt2_ld);
+}
+
+int scnattn_attn_datt1_post_blocks(int B, int P) { return attn_datt1_post_blocks(B, P); }
+
+int scnattn_attn_datt1_post(void* stream, int B, int P, int A, int T, const int32_t* dl, const float* att1,
+                            const float* att2_all, const float* de_all, const float* w, float* datt1,
+                            float* dwpart) {
+    return attn_datt1_post(ST(stream), B, P, A, T, dl, att1, att2_all, de_all, w, datt1, dwpart, nullptr);
+}
+
+int scnattn_scn_mix_fwd(void* stream, int rows, int F4, const float* pz, int pz_nslab, long pz_stride, long pz_ld,
+                        const float* ex, const float* ph, int ph_nslab, long ph_stride, long ph_ld,
+                        const float* qx, const float* qh, float* pa, float* phs, float* xcat) {
+    return scn_mix_fwd(ST(stream), rows, F4, Slabs{pz, pz_nslab, pz_stride, pz_ld}, ex,
+                       Slabs{ph, ph_nslab, ph_stride, ph_ld}, qx, qh, pa, phs, xcat);
+}
+
+int scnattn_lstm_fwd(void* stream, int rows, int H, const float* r, int nslab, long slab_stride, long r_ld,
+                     long r_gate_stride, const float* bih, const float* bhh, const float* c_prev, float* gates,
+                     float* c_new, float* h_new, float* tanhc) {
+    return lstm_fwd(ST(stream), rows, H, Slabs{r, nslab, slab_stride, r_ld}, r_gate_stride, bih, bhh, c_prev, gates,
+                    c_new, h_new, tanhc);
+}
+
+int scnattn_lstm_bwd(void* stream, int rows, int rows_next, int H, const float* dh_fc, const float* dh_next,
+                     int nslab, long slab_stride, long dh_ld, float* dc, const float* gates, const float* c_prev,
+                     const float* tanhc, float* dr) {
+    return lstm_bwd(ST(stream), rows, rows_next, H, dh_fc, Slabs{dh_next, nslab, slab_stride, dh_ld}, dc, gates,
+                    c_prev, tanhc, dr);
+}
+
+int scnattn_scn_mix_bwd(void* stream, int rows, int F4, const float* dxcat, int nslab, long slab_stride, long dx_ld,
+                        long dx_gate_stride, const float* qx, const float* qh, const float* pa, const float* phs,
+                        float* dpx, float* dph, long dph_ld, float* dqx_acc, float* dqh_acc) {
+    return scn_mix_bwd(ST(stream), rows, F4, Slabs{dxcat, nslab, slab_stride, dx_ld}, dx_gate_stride, qx, qh, pa, phs,
+                       dpx, dph, dph_ld, dqx_acc, dqh_acc);
+}
+
+int scnattn_gate_bwd(void* stream, int rows, int E, const float* dz, int nslab, long slab_stride, long dz_ld,
+                     const float* awe, const float* gate, float* dawe, float* dgpre, long dgpre_ld) {
+    return gate_bwd(ST(stream), rows, E, Slabs{dz, nslab, slab_stride, dz_ld}, awe, gate, dawe, dgpre, dgpre_ld);
+}
+
+int scnattn_transpose2d(void* stream, int R, int C, const float* in, long ldi, float* out, long ldo) {
+    return transpose2d(ST(stream), R, C, in, ldi, out, ldo);
+}
+
+int scnattn_colsum(void* stream, int R, int N, const float* X, long ld, float* out, float beta) {
+    return colsum(ST(stream), R, N, X, ld, out, beta);
+}
+
+int scnattn_mul_bcast(void* stream, int T, int B, int N, const float* x, const float* q, float* out) {
+    return mul_bcast(ST(stream), T, B, N, x, q, out);
+}
+
+int scnattn_pool_permute_fwd(void* stream, int B, int C, int Hin, int Win, int Ho, int Wo, const float* x,
+                             long sxb, long sxc, long sxh, long sxw, float* y) {
+    return pool_permute_fwd(ST(stream), B, C, Hin, Win, Ho, Wo, x, sxb, sxc, sxh, sxw, y);
+}
+
+int scnattn_pool_permute_bwd(void* stream, int B, int C, int Hin, int Win, int Ho, int Wo, const float* dy,
+                             float* dx, long sxb, long sxc, long sxh, long sxw) {
+    return pool_permute_bwd(ST(stream), B, C, Hin, Win, Ho, Wo, dy, dx, sxb, sxc, sxh, sxw);
+}
+
+int scnattn_clamp_adam(void* stream, long n, float* p, const float* g, float* m, float* v, double lr,
+                       double beta1, double beta2, double eps, int step, double clip, double gscale) {
+    return clamp_adam(ST(stream), n, p, g, m, v, lr, beta1, beta2, eps, step, clip, gscale);
+}
+
+}  // extern "C"

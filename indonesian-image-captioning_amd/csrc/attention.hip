@@ -1,0 +1,455 @@
+// Soft-attention kernels (forward and backward) for the decode step.
+// Reference math: models/attention.py:35-44 and the gate of models/decoders/attention_scn.py:147-148.
+//
+// The time-invariant projection att1 = encoder_att(enc) is computed ONCE per sequence by sgemm (the
+// reference recomputes it every timestep); the kernels here are the HBM-bound streaming parts:
+//   attn_scores   : reads att1 (B*P*A floats) once, one wave per pixel row, 16 B per lane
+//   attn_context  : softmax + the weighted sum over the 14x14 grid; reads enc (B*P*E floats) once,
+//                   a wave covers 1 KiB of one pixel row per load instruction, 8 waves interleave p
+//   attn_dalpha   : backward mirror of attn_context (dot products of enc rows with dawe)
+//   attn_softmax_bwd / attn_datt1_post : ReLU mask is RECOMPUTED from att1 + att2_t instead of
+//                   storing the (b,196,512) activation per step as autograd does in the reference.
+// None of these has data reuse across lanes, so operands go HBM -> VGPR directly; LDS only holds the
+// per-row vectors every wave re-reads (att2, w, alpha, dawe).
+#include "common.h"
+#include "kernels.h"
+
+namespace scn {
+
+namespace {
+
+constexpr int PC = 16;  // pixel rows per workgroup in the row-dot kernels (4 waves x 4 rows)
+
+__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
+    // red: >= 16 floats of LDS; all threads get the result
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    v = is_max ? wave_max(v) : wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int i = 1; i < nw; ++i) r = is_max ? fmaxf(r, red[i]) : r + red[i];
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(256) void attn_scores_kernel(int rows, int P, int A, const float* __restrict__ att1,
+                                                          Slabs att2, const float* __restrict__ bd,
+                                                          const float* __restrict__ w, const float* __restrict__ b0,
+                                                          float* __restrict__ e, float* __restrict__ att2_out) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int A4 = (A + 3) & ~3;
+    float* att2s = sm;
+    float* ws = sm + A4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, p0 = blockIdx.x * PC;
+    for (int a = tid; a < A4; a += 256) {
+        float v = 0.f, wv = 0.f;
+        if (a < A) {
+            v = slab_sum(att2.p, (long)b * att2.ld + a, att2.n, att2.stride) + (bd ? bd[a] : 0.f);
+            wv = w[a];
+            if (blockIdx.x == 0 && att2_out) att2_out[(long)b * A + a] = v;
+        }
+        att2s[a] = v;
+        ws[a] = wv;
+    }
+    __syncthreads();
+    // each wave: 4 pixel rows, independent accumulators (4 x 16 B loads in flight per lane)
+    const float* rowp[4];
+    bool ok[4];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = p0 + wave * 4 + j;
+        ok[j] = p < P;
+        rowp[j] = att1 + ((long)b * P + (ok[j] ? p : P - 1)) * A;
+    }
+    if (VEC) {
+        for (int a = lane * 4; a < A; a += 256) {
+            const f32x4 s2 = *reinterpret_cast<const f32x4*>(att2s + a);
+            const f32x4 ww = *reinterpret_cast<const f32x4*>(ws + a);
+            f32x4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4*>(rowp[j] + a);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[j] = fmaf(fmaxf(v[j][c] + s2[c], 0.f), ww[c], acc[j]);
+        }
+    } else {
+        for (int a = lane; a < A; a += 64) {
+            const float s2 = att2s[a], ww = ws[a];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = fmaf(fmaxf(rowp[j][a] + s2, 0.f), ww, acc[j]);
+        }
+    }
+    const float bias0 = b0 ? b0[0] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float s = wave_sum(acc[j]);
+        if (lane == 0 && ok[j]) e[(long)b * P + p0 + wave * 4 + j] = s + bias0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MODE 0: softmax-weighted sum (+ optional sigmoid gate).  MODE 1: plain mean over pixels.
+template <bool VEC, int MODE>
+__global__ __launch_bounds__(512) void attn_context_kernel(int rows, int P, int E, const float* __restrict__ enc,
+                                                           const float* __restrict__ e, Slabs gpre,
+                                                           const float* __restrict__ bbeta,
+                                                           float* __restrict__ alpha_out, long alpha_ld,
+                                                           float* __restrict__ alpha_save, float* __restrict__ awe,
+                                                           float* __restrict__ gate, float* __restrict__ z) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* part = sm;              // [8][256]
+    float* red = sm + 8 * 256;     // [16]
+    float* alph = red + 16;        // [P]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, e0 = blockIdx.x * 256;
+
+    if (MODE == 0) {
+        float m = -INFINITY;
+        for (int p = tid; p < P; p += 512) m = fmaxf(m, e[(long)b * P + p]);
+        m = block_reduce(m, red, true);
+        float s = 0.f;
+        for (int p = tid; p < P; p += 512) {
+            const float ex = expf(e[(long)b * P + p] - m);
+            alph[p] = ex;
+            s += ex;
+        }
+        s = block_reduce(s, red, false);
+        for (int p = tid; p < P; p += 512) {
+            const float a = alph[p] / s;
+            alph[p] = a;
+            if (blockIdx.x == 0) {
+                if (alpha_out) alpha_out[(long)b * alpha_ld + p] = a;
+                if (alpha_save) alpha_save[(long)b * P + p] = a;
+            }
+        }
+        __syncthreads();
+    }
+
+    const int col = e0 + lane * 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* base = enc + (long)b * P * E;
+    if (VEC) {
+        const int cc = min(col, E - 4);
+        const bool cok = col < E;
+        for (int p = wave; p < P; p += 32) {
+            f32x4 v[4];
+            float al[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int pp = p + 8 * j;
+                v[j] = *reinterpret_cast<const f32x4*>(base + (long)min(pp, P - 1) * E + cc);
+                al[j] = (pp < P && cok) ? (MODE == 0 ? alph[min(pp, P - 1)] : 1.f) : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = fmaf(al[j], v[j][c], acc[c]);
+        }
+    } else {
+        for (int p = wave; p < P; p += 8) {
+            const float al = MODE == 0 ? alph[p] : 1.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (col + c < E) acc[c] = fmaf(al, base[(long)p * E + col + c], acc[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) part[wave * 256 + lane * 4 + c] = acc[c];
+    __syncthreads();
+    if (tid < 256) {
+        const int c = e0 + tid;
+        if (c < E) {
+            float a = part[tid];
+#pragma unroll
+            for (int w8 = 1; w8 < 8; ++w8) a += part[w8 * 256 + tid];
+            if (MODE == 1) {
+                awe[(long)b * E + c] = a / (float)P;
+            } else {
+                awe[(long)b * E + c] = a;
+                if (gpre.p) {
+                    const float gp = slab_sum(gpre.p, (long)b * gpre.ld + c, gpre.n, gpre.stride) + (bbeta ? bbeta[c] : 0.f);
+                    const float g = sigmoidf_(gp);
+                    if (gate) gate[(long)b * E + c] = g;
+                    if (z) z[(long)b * E + c] = g * a;
+                } else if (z) {
+                    z[(long)b * E + c] = a;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(256) void attn_dalpha_kernel(int rows, int P, int E, const float* __restrict__ enc,
+                                                          const float* __restrict__ dawe,
+                                                          const float* __restrict__ dalpha_in, long din_ld,
+                                                          float* __restrict__ dalpha) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int E4 = (E + 3) & ~3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, p0 = blockIdx.x * PC;
+    for (int c = tid; c < E4; c += 256) sm[c] = c < E ? dawe[(long)b * E + c] : 0.f;
+    __syncthreads();
+    const float* rowp[4];
+    bool ok[4];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = p0 + wave * 4 + j;
+        ok[j] = p < P;
+        rowp[j] = enc + ((long)b * P + (ok[j] ? p : P - 1)) * E;
+    }
+    if (VEC) {
+        for (int c = lane * 4; c < E; c += 256) {
+            const f32x4 d = *reinterpret_cast<const f32x4*>(sm + c);
+            f32x4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4*>(rowp[j] + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[j] = fmaf(v[j][k], d[k], acc[j]);
+        }
+    } else {
+        for (int c = lane; c < E; c += 64) {
+            const float d = sm[c];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = fmaf(rowp[j][c], d, acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float s = wave_sum(acc[j]);
+        const int p = p0 + wave * 4 + j;
+        if (lane == 0 && ok[j]) dalpha[(long)b * P + p] = s + (dalpha_in ? dalpha_in[(long)b * din_ld + p] : 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(int rows, int P, int A, const float* __restrict__ att1,
+                                                               const float* __restrict__ att2,
+                                                               const float* __restrict__ w,
+                                                               const float* __restrict__ alpha,
+                                                               const float* __restrict__ dalpha,
+                                                               float* __restrict__ de, float* __restrict__ datt2,
+                                                               long datt2_ld) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* part = sm;              // [16][64]
+    float* red = sm + 16 * 64;     // [16]
+    float* des = red + 16;         // [P]
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y, a0 = blockIdx.x * 64;
+    float dot = 0.f;
+    for (int p = tid; p < P; p += 256) dot = fmaf(alpha[(long)b * P + p], dalpha[(long)b * P + p], dot);
+    dot = block_reduce(dot, red, false);
+    for (int p = tid; p < P; p += 256) {
+        const float d = alpha[(long)b * P + p] * (dalpha[(long)b * P + p] - dot);
+        des[p] = d;
+        if (blockIdx.x == 0 && de) de[(long)b * P + p] = d;
+    }
+    __syncthreads();
+    const int grp = tid >> 4, q = tid & 15;
+    const int a = a0 + q * 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float s2[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s2[c] = (a + c < A) ? att2[(long)b * A + a + c] : 0.f;
+    const float* base = att1 + (long)b * P * A;
+    if (VEC) {
+        const int ac = min(a, A - 4);
+        const bool aok = a < A;
+        for (int p = grp; p < P; p += 64) {
+            f32x4 v[4];
+            float d[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int pp = p + 16 * j;
+                v[j] = *reinterpret_cast<const f32x4*>(base + (long)min(pp, P - 1) * A + ac);
+                d[j] = (pp < P && aok) ? des[min(pp, P - 1)] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] += (v[j][c] + s2[c] > 0.f) ? d[j] : 0.f;
+        }
+    } else {
+        for (int p = grp; p < P; p += 16) {
+            const float d = des[p];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (a + c < A) acc[c] += (base[(long)p * A + a + c] + s2[c] > 0.f) ? d : 0.f;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) part[grp * 64 + q * 4 + c] = acc[c];
+    __syncthreads();
+    if (tid < 64 && a0 + tid < A) {
+        float s = part[tid];
+#pragma unroll
+        for (int g2 = 1; g2 < 16; ++g2) s += part[g2 * 64 + tid];
+        datt2[(long)b * datt2_ld + a0 + tid] = w[a0 + tid] * s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+constexpr int PC2 = 8;
+
+__global__ __launch_bounds__(256) void attn_datt1_post_kernel(int B, int P, int A, int T, const int* __restrict__ dl,
+                                                              const float* __restrict__ att1,
+                                                              const float* __restrict__ att2_all,
+                                                              const float* __restrict__ de_all,
+                                                              const float* __restrict__ w, float* __restrict__ datt1,
+                                                              float* __restrict__ dwpart) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // de_s[T][PC2]
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y, p0 = blockIdx.x * PC2;
+    const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+    int Tb = dl[b];
+    if (Tb > T) Tb = T;
+    for (int i = tid; i < T * PC2; i += 256) {
+        const int t = i / PC2, j = i - t * PC2;
+        sm[i] = (t < Tb && p0 + j < P) ? de_all[((long)t * B + b) * P + p0 + j] : 0.f;
+    }
+    __syncthreads();
+    for (int a = tid; a < A; a += 256) {
+        float a1[PC2], acc[PC2];
+#pragma unroll
+        for (int j = 0; j < PC2; ++j) {
+            a1[j] = att1[((long)b * P + min(p0 + j, P - 1)) * A + a];
+            acc[j] = 0.f;
+        }
+        float dwacc = 0.f;
+        for (int t = 0; t < Tb; ++t) {
+            const float s2 = att2_all[((long)t * B + b) * A + a];
+#pragma unroll
+            for (int j = 0; j < PC2; ++j) {
+                const float s = a1[j] + s2;
+                const float d = sm[t * PC2 + j];
+                if (s > 0.f) {
+                    acc[j] += d;
+                    dwacc = fmaf(d, s, dwacc);
+                }
+            }
+        }
+        const float wa = w[a];
+#pragma unroll
+        for (int j = 0; j < PC2; ++j)
+            if (p0 + j < P) datt1[((long)b * P + p0 + j) * A + a] = wa * acc[j];
+        dwpart[(long)blk * (A + 1) + a] = dwacc;
+    }
+    if (tid == 0) {
+        float s = 0.f;
+        for (int i = 0; i < Tb * PC2; ++i) s += sm[i];
+        dwpart[(long)blk * (A + 1) + A] = s;
+    }
+}
+
+}  // namespace
+
+// ================================================================================================
+int attn_scores(hipStream_t st, int rows, int P, int A, const float* att1, Slabs att2, const float* bd,
+                const float* w, const float* b0, float* e, float* att2_out) {
+    if (rows <= 0) return 0;
+    SCN_ARG(att1 && att2.p && w && e && P > 0 && A > 0, "attn_scores: bad argument");
+    dim3 grid(cdiv(P, PC), rows), block(256);
+    const size_t lds = 2 * ((A + 3) & ~3) * sizeof(float);
+    SCN_ARG(lds <= 64 * 1024, "attn_scores: attention_dim too large for the LDS staging");
+    if (A % 4 == 0 && aligned16(att1))
+        hipLaunchKernelGGL(attn_scores_kernel<true>, grid, block, lds, st, rows, P, A, att1, att2, bd, w, b0, e, att2_out);
+    else
+        hipLaunchKernelGGL(attn_scores_kernel<false>, grid, block, lds, st, rows, P, A, att1, att2, bd, w, b0, e, att2_out);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
+int attn_context(hipStream_t st, int rows, int P, int E, const float* enc, const float* e, Slabs gpre,
+                 const float* bbeta, float* alpha_out, long alpha_ld, float* alpha_save, float* awe,
+                 float* gate, float* z) {
+    if (rows <= 0) return 0;
+    SCN_ARG(enc && e && awe && P > 0 && E > 0, "attn_context: bad argument");
+    dim3 grid(cdiv(E, 256), rows), block(512);
+    const size_t lds = (8 * 256 + 16 + P) * sizeof(float);
+    SCN_ARG(lds <= 64 * 1024, "attn_context: num_pixels too large for the LDS staging");
+    if (E % 4 == 0 && aligned16(enc))
+        hipLaunchKernelGGL((attn_context_kernel<true, 0>), grid, block, lds, st, rows, P, E, enc, e, gpre, bbeta,
+                           alpha_out, alpha_ld, alpha_save, awe, gate, z);
+    else
+        hipLaunchKernelGGL((attn_context_kernel<false, 0>), grid, block, lds, st, rows, P, E, enc, e, gpre, bbeta,
+                           alpha_out, alpha_ld, alpha_save, awe, gate, z);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
+int mean_pixels(hipStream_t st, int rows, int P, int E, const float* enc, float* out) {
+    if (rows <= 0) return 0;
+    SCN_ARG(enc && out && P > 0 && E > 0, "mean_pixels: bad argument");
+    dim3 grid(cdiv(E, 256), rows), block(512);
+    const size_t lds = (8 * 256 + 16 + P) * sizeof(float);
+    Slabs none{nullptr, 0, 0, 0};
+    if (E % 4 == 0 && aligned16(enc))
+        hipLaunchKernelGGL((attn_context_kernel<true, 1>), grid, block, lds, st, rows, P, E, enc, (const float*)nullptr,
+                           none, (const float*)nullptr, (float*)nullptr, 0L, (float*)nullptr, out, (float*)nullptr,
+                           (float*)nullptr);
+    else
+        hipLaunchKernelGGL((attn_context_kernel<false, 1>), grid, block, lds, st, rows, P, E, enc, (const float*)nullptr,
+                           none, (const float*)nullptr, (float*)nullptr, 0L, (float*)nullptr, out, (float*)nullptr,
+                           (float*)nullptr);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
+int attn_dalpha(hipStream_t st, int rows, int P, int E, const float* enc, const float* dawe,
+                const float* dalpha_in, long dalpha_in_ld, float* dalpha) {
+    if (rows <= 0) return 0;
+    SCN_ARG(enc && dawe && dalpha && P > 0 && E > 0, "attn_dalpha: bad argument");
+    dim3 grid(cdiv(P, PC), rows), block(256);
+    const size_t lds = ((E + 3) & ~3) * sizeof(float);
+    SCN_ARG(lds <= 64 * 1024, "attn_dalpha: encoder_dim too large for the LDS staging");
+    if (E % 4 == 0 && aligned16(enc))
+        hipLaunchKernelGGL(attn_dalpha_kernel<true>, grid, block, lds, st, rows, P, E, enc, dawe, dalpha_in, dalpha_in_ld, dalpha);
+    else
+        hipLaunchKernelGGL(attn_dalpha_kernel<false>, grid, block, lds, st, rows, P, E, enc, dawe, dalpha_in, dalpha_in_ld, dalpha);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
+int attn_softmax_bwd(hipStream_t st, int rows, int P, int A, const float* att1, const float* att2,
+                     const float* w, const float* alpha, const float* dalpha, float* de, float* datt2,
+                     long datt2_ld) {
+    if (rows <= 0) return 0;
+    SCN_ARG(att1 && att2 && w && alpha && dalpha && datt2 && P > 0 && A > 0, "attn_softmax_bwd: bad argument");
+    dim3 grid(cdiv(A, 64), rows), block(256);
+    const size_t lds = (16 * 64 + 16 + P) * sizeof(float);
+    SCN_ARG(lds <= 64 * 1024, "attn_softmax_bwd: num_pixels too large for the LDS staging");
+    if (A % 4 == 0 && aligned16(att1))
+        hipLaunchKernelGGL(attn_softmax_bwd_kernel<true>, grid, block, lds, st, rows, P, A, att1, att2, w, alpha, dalpha, de, datt2, datt2_ld);
+    else
+        hipLaunchKernelGGL(attn_softmax_bwd_kernel<false>, grid, block, lds, st, rows, P, A, att1, att2, w, alpha, dalpha, de, datt2, datt2_ld);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
+int attn_datt1_post(hipStream_t st, int B, int P, int A, int T, const int* dl, const float* att1,
+                    const float* att2_all, const float* de_all, const float* w, float* datt1,
+                    float* dwpart, int* nblocks_out) {
+    SCN_ARG(B > 0 && P > 0 && A > 0 && T > 0, "attn_datt1_post: bad dims");
+    SCN_ARG(dl && att1 && att2_all && de_all && w && datt1 && dwpart, "attn_datt1_post: null operand");
+    dim3 grid(cdiv(P, PC2), B), block(256);
+    const size_t lds = (size_t)T * PC2 * sizeof(float);
+    SCN_ARG(lds <= 64 * 1024, "attn_datt1_post: too many timesteps for the LDS staging");
+    if (nblocks_out) *nblocks_out = grid.x * grid.y;
+    hipLaunchKernelGGL(attn_datt1_post_kernel, grid, block, lds, st, B, P, A, T, dl, att1, att2_all, de_all, w, datt1, dwpart);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
+int attn_datt1_post_blocks(int B, int P) { return cdiv(P, PC2) * B; }
+
+}  // namespace scn

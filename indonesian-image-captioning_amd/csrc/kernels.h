@@ -1,0 +1,85 @@
+// Internal launcher API of libscnattn: one function per kernel, all asynchronous on `st`,
+// all returning 0 or an error code (message via scn::last_error()).  The extern "C" surface in
+// api.cpp and the sequence drivers in sequence.cpp are thin layers over these.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define SCN_MAX_KSPLIT 16
+
+namespace scn {
+
+// ---- sgemm.hip -------------------------------------------------------------------------------
+int sgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, const float* A, long lda,
+          const float* B, long ldb, float beta, float* C, long ldc, const float* bias,
+          const float* rowmask, int batch, long sA, long sB, long sC);
+
+// ---- skinny.hip ------------------------------------------------------------------------------
+int skinny_pick_ksplit(int rows, int N, int K, int groups);
+int skinny_gemm(hipStream_t st, int rows, int N, int K, int groups, const float* X, long ldx, long xg,
+                const float* W, long ldw, long wg, float* Y, long ldy, long yg, long yslab, int ksplit);
+
+// A split-K result: `n` slabs `stride` elements apart, row leading dimension `ld`.
+struct Slabs {
+    const float* p; int n; long stride; long ld;
+};
+
+// ---- attention.hip ---------------------------------------------------------------------------
+// e[b,p] = w . relu(att1[b,p,:] + att2[b,:]) + b0, att2 = sum(slabs) + bd   (attention.py:37-39)
+int attn_scores(hipStream_t st, int rows, int P, int A, const float* att1, Slabs att2, const float* bd,
+                const float* w, const float* b0, float* e, float* att2_out);
+// alpha = softmax_p(e); awe = sum_p alpha*enc; z = sigmoid(gpre + bbeta) * awe   (attention.py:40-42,
+// attention_scn.py:147-148).  gpre.p == nullptr -> no gate (z = awe, gate not written).
+int attn_context(hipStream_t st, int rows, int P, int E, const float* enc, const float* e, Slabs gpre,
+                 const float* bbeta, float* alpha_out, long alpha_ld, float* alpha_save, float* awe,
+                 float* gate, float* z);
+int mean_pixels(hipStream_t st, int rows, int P, int E, const float* enc, float* out);
+// dalpha[b,p] = enc[b,p,:] . dawe[b,:] + dalpha_in[b,p]
+int attn_dalpha(hipStream_t st, int rows, int P, int E, const float* enc, const float* dawe,
+                const float* dalpha_in, long dalpha_in_ld, float* dalpha);
+// de = alpha*(dalpha - sum(alpha*dalpha));  datt2[b,a] = w[a] * sum_p de[b,p]*[att1+att2 > 0]
+int attn_softmax_bwd(hipStream_t st, int rows, int P, int A, const float* att1, const float* att2,
+                     const float* w, const float* alpha, const float* dalpha, float* de, float* datt2,
+                     long datt2_ld);
+// After the time loop: datt1[b,p,a] = w[a]*sum_t de_t[b,p]*[att1+att2_t>0]; per-block partials of
+// dw[a] = sum de_t*relu(att1+att2_t) and db0 = sum de_t in dwpart[block][A+1].
+int attn_datt1_post(hipStream_t st, int B, int P, int A, int T, const int* dl, const float* att1,
+                    const float* att2_all, const float* de_all, const float* w, float* datt1,
+                    float* dwpart, int* nblocks_out);
+int attn_datt1_post_blocks(int B, int P);
+
+// ---- scn_cell.hip ----------------------------------------------------------------------------
+int scn_mix_fwd(hipStream_t st, int rows, int F4, Slabs pz, const float* ex, Slabs ph, const float* qx,
+                const float* qh, float* pa, float* phs, float* xcat);
+int lstm_fwd(hipStream_t st, int rows, int H, Slabs r, long r_g, const float* bih, const float* bhh,
+             const float* c_prev, float* gates, float* c_new, float* h_new, float* tanhc);
+int lstm_bwd(hipStream_t st, int rows, int rows_next, int H, const float* dh_fc, Slabs dh_next,
+             float* dc, const float* gates, const float* c_prev, const float* tanhc, float* dr);
+int scn_mix_bwd(hipStream_t st, int rows, int F4, Slabs dxcat, long dxcat_g, const float* qx,
+                const float* qh, const float* pa, const float* phs, float* dpx, float* dph, long dph_ld,
+                float* dqx_acc, float* dqh_acc);
+int gate_bwd(hipStream_t st, int rows, int E, Slabs dz, const float* awe, const float* gate,
+             float* dawe, float* dgpre, long dgpre_ld);
+
+// ---- misc.hip --------------------------------------------------------------------------------
+int transpose2d(hipStream_t st, int R, int C, const float* in, long ldi, float* out, long ldo);
+int copy2d(hipStream_t st, int R, int C, const float* in, long ldi, float* out, long ldo);
+int colsum(hipStream_t st, int R, int N, const float* X, long ld, float* out, float beta);
+int gather_rows_tm(hipStream_t st, int B, int T, int L, int M, const long long* caps, const float* table,
+                   int V, float* out_tm);
+int scatter_add_rows_tm(hipStream_t st, int B, int T, int L, int M, const long long* caps, const int* dl,
+                        const float* demb_tm, int V, float* dtable);
+int hidden_to_bm(hipStream_t st, int B, int T, int D, const int* dl, const float* hs_tm,
+                 const float* mask_bm, float* out_bm, float* rowmask);
+int hidden_from_bm(hipStream_t st, int B, int T, int D, const int* dl, const float* dbm,
+                   const float* mask_bm, float* out_tm);
+int add_bcast_rows(hipStream_t st, int B, int P, int E, const float* v, float scale, float* x);
+int pool_permute_fwd(hipStream_t st, int B, int C, int Hin, int Win, int Ho, int Wo, const float* x,
+                     long sxb, long sxc, long sxh, long sxw, float* y);
+int pool_permute_bwd(hipStream_t st, int B, int C, int Hin, int Win, int Ho, int Wo, const float* dy,
+                     float* dx, long sxb, long sxc, long sxh, long sxw);
+int clamp_adam(hipStream_t st, long n, float* p, const float* g, float* m, float* v, double lr, double b1,
+               double b2, double eps, int step, double clip, double gscale);
+int mul_bcast(hipStream_t st, int T, int B, int N, const float* x, const float* q, float* out);
+int reduce_slabs(hipStream_t st, int rows, int N, Slabs s, float* out);
+
+}  // namespace scn

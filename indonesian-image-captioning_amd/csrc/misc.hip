@@ -1,0 +1,327 @@
+// Data-movement and reduction helpers around the hot kernels: weight re-layout for the streaming
+// GEMMs, column sums for bias gradients, embedding gather/scatter in time-major order, the
+// dropout/transposition between the time-major recurrence and the batch-major `fc` GEMM, the
+// encoder's AdaptiveAvgPool2d(14)+permute (models/encoders/caption.py:41-43), and the fused
+// clamp(+-c) + Adam update (utils/optimizer.py:1-11 + torch.optim.Adam, trains/attention_scn.py:244-252).
+#include "common.h"
+#include "kernels.h"
+
+namespace scn {
+
+namespace {
+
+__global__ __launch_bounds__(256) void transpose2d_kernel(int R, int C, const float* __restrict__ in, long ldi,
+                                                          float* __restrict__ out, long ldo) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        tile[ty + 8 * i][tx] = (r < R && c < C) ? in[(long)r * ldi + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (c < C && r < R) out[(long)c * ldo + r] = tile[tx][ty + 8 * i];
+    }
+}
+
+__global__ __launch_bounds__(256) void copy2d_kernel(int R, int C, const float* __restrict__ in, long ldi,
+                                                     float* __restrict__ out, long ldo) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)R * C) return;
+    const int r = (int)(i / C), c = (int)(i - (long)r * C);
+    out[(long)r * ldo + c] = in[(long)r * ldi + c];
+}
+
+// out[n] = beta*out[n] + sum_r X[r][n]; one workgroup per 64 columns, 4 row lanes, fixed order.
+__global__ __launch_bounds__(256) void colsum_kernel(int R, int N, const float* __restrict__ X, long ld,
+                                                     float* __restrict__ out, float beta) {
+    __shared__ float part[4][64];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + c;
+    float s = 0.f;
+    if (n < N)
+        for (int r = rl; r < R; r += 4) s += X[(long)r * ld + n];
+    part[rl][c] = s;
+    __syncthreads();
+    if (rl == 0 && n < N) {
+        const float v = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
+        out[n] = (beta != 0.f ? beta * out[n] : 0.f) + v;
+    }
+}
+
+// out_tm[t][b][:] = table[caps[b][t]][:]   (embedding lookup, attention_scn.py:124, time-major)
+__global__ __launch_bounds__(256) void gather_rows_kernel(int B, int T, int L, int M, const long long* __restrict__ caps,
+                                                          const float* __restrict__ table, int V,
+                                                          float* __restrict__ out) {
+    const int row = blockIdx.x;  // t*B + b
+    const int t = row / B, b = row - t * B;
+    long long tok = caps[(long)b * L + t];
+    if (tok < 0) tok = 0;
+    if (tok >= V) tok = V - 1;
+    const float* src = table + tok * M;
+    float* dst = out + (long)row * M;
+    for (int m = threadIdx.x; m < M; m += 256) dst[m] = src[m];
+}
+
+// dtable[caps[b][t]][:] += demb_tm[t][b][:] for active (t < dl[b]) cells.  One workgroup per
+// (token-owning) cell; duplicates are resolved with float atomics (order-dependent in the last bit).
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(int B, int T, int L, int M,
+                                                               const long long* __restrict__ caps,
+                                                               const int* __restrict__ dl,
+                                                               const float* __restrict__ demb, int V,
+                                                               float* __restrict__ dtable) {
+    const int row = blockIdx.x;
+    const int t = row / B, b = row - t * B;
+    if (t >= dl[b]) return;
+    long long tok = caps[(long)b * L + t];
+    if (tok < 0 || tok >= V) return;
+    const float* src = demb + (long)row * M;
+    float* dst = dtable + tok * M;
+    for (int m = threadIdx.x; m < M; m += 256) atomicAdd(dst + m, src[m]);
+}
+
+// out_bm[b][t][:] = (t < dl[b]) ? hs_tm[t][b][:] * mask[b][t][:] : 0 ; rowmask[b*T+t] = t < dl[b]
+__global__ __launch_bounds__(256) void hidden_to_bm_kernel(int B, int T, int D, const int* __restrict__ dl,
+                                                           const float* __restrict__ hs, const float* __restrict__ mask,
+                                                           float* __restrict__ out, float* __restrict__ rowmask) {
+    const int row = blockIdx.x;  // b*T + t
+    const int b = row / T, t = row - b * T;
+    const bool act = t < dl[b];
+    if (threadIdx.x == 0 && rowmask) rowmask[row] = act ? 1.f : 0.f;
+    const float* src = hs + ((long)t * B + b) * D;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float v = 0.f;
+        if (act) v = src[d] * (mask ? mask[(long)row * D + d] : 1.f);
+        out[(long)row * D + d] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void hidden_from_bm_kernel(int B, int T, int D, const int* __restrict__ dl,
+                                                             const float* __restrict__ dbm, const float* __restrict__ mask,
+                                                             float* __restrict__ out) {
+    const int row = blockIdx.x;  // t*B + b
+    const int t = row / B, b = row - t * B;
+    const bool act = t < dl[b];
+    const long src = ((long)b * T + t) * D;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float v = 0.f;
+        if (act) v = dbm[src + d] * (mask ? mask[src + d] : 1.f);
+        out[(long)row * D + d] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void add_bcast_rows_kernel(int B, int P, int E, const float* __restrict__ v,
+                                                             float scale, float* __restrict__ x) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * P * E) return;
+    const int e = (int)(i % E);
+    const int b = (int)(i / ((long)P * E));
+    x[i] += scale * v[(long)b * E + e];
+}
+
+// AdaptiveAvgPool2d window of output index o over n_in -> n_out: [floor(o*n_in/n_out), ceil((o+1)*n_in/n_out))
+__device__ __forceinline__ void pool_window(int o, int n_in, int n_out, int& lo, int& hi) {
+    lo = (o * n_in) / n_out;
+    hi = ((o + 1) * n_in + n_out - 1) / n_out;
+}
+
+// y[b][oh][ow][c] = mean over the window of x[b][c][:, :]; x addressed through explicit strides so
+// both NCHW-contiguous and channels-last trunks are read in place.  Threads run along c (the
+// contiguous dimension of y, and of a channels-last x).
+__global__ __launch_bounds__(256) void pool_permute_fwd_kernel(int B, int C, int Hin, int Win, int Ho, int Wo,
+                                                               const float* __restrict__ x, long sxb, long sxc,
+                                                               long sxh, long sxw, float* __restrict__ y) {
+    const int cell = blockIdx.x;  // (b*Ho + oh)*Wo + ow
+    const int ow = cell % Wo, oh = (cell / Wo) % Ho, b = cell / (Wo * Ho);
+    int h0, h1, w0, w1;
+    pool_window(oh, Hin, Ho, h0, h1);
+    pool_window(ow, Win, Wo, w0, w1);
+    const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int h = h0; h < h1; ++h)
+            for (int w = w0; w < w1; ++w) s += x[b * sxb + c * sxc + h * sxh + w * sxw];
+        y[(long)cell * C + c] = s * inv;
+    }
+}
+
+// dx[b][c][h][w] = sum over output cells whose window contains (h,w) of dy/|window|
+__global__ __launch_bounds__(256) void pool_permute_bwd_kernel(int B, int C, int Hin, int Win, int Ho, int Wo,
+                                                               const float* __restrict__ dy, float* __restrict__ dx,
+                                                               long sxb, long sxc, long sxh, long sxw) {
+    const int cell = blockIdx.x;  // (b*Hin + h)*Win + w
+    const int w = cell % Win, h = (cell / Win) % Hin, b = cell / (Win * Hin);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int oh = 0; oh < Ho; ++oh) {
+            int h0, h1;
+            pool_window(oh, Hin, Ho, h0, h1);
+            if (h < h0 || h >= h1) continue;
+            for (int ow = 0; ow < Wo; ++ow) {
+                int w0, w1;
+                pool_window(ow, Win, Wo, w0, w1);
+                if (w < w0 || w >= w1) continue;
+                s += dy[(((long)b * Ho + oh) * Wo + ow) * C + c] / (float)((h1 - h0) * (w1 - w0));
+            }
+        }
+        dx[b * sxb + c * sxc + h * sxh + w * sxw] = s;
+    }
+}
+
+// g <- clamp(g*gscale, -clip, clip); Adam(m, v, p) with bias correction, one pass over a flat buffer
+__global__ __launch_bounds__(256) void clamp_adam_kernel(long n, float* __restrict__ p, const float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v, float lr,
+                                                         float b1, float b2, float eps, float bc1, float sqrt_bc2,
+                                                         float clip, float gscale) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float gi = g[i] * gscale;
+        if (clip > 0.f) gi = fminf(fmaxf(gi, -clip), clip);
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / sqrt_bc2 + eps;
+        p[i] -= (lr / bc1) * (mi / denom);
+    }
+}
+
+// out[t][b][n] = x[t][b][n] * q[b][n]
+__global__ __launch_bounds__(256) void mul_bcast_kernel(int T, int B, int N, const float* __restrict__ x,
+                                                        const float* __restrict__ q, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)T * B * N) return;
+    out[i] = x[i] * q[i % ((long)B * N)];
+}
+
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(int rows, int N, Slabs s, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)rows * N) return;
+    const int r = (int)(i / N), c = (int)(i - (long)r * N);
+    out[i] = slab_sum(s.p, (long)r * s.ld + c, s.n, s.stride);
+}
+
+}  // namespace
+
+int mul_bcast(hipStream_t st, int T, int B, int N, const float* x, const float* q, float* out) {
+    if (T <= 0 || B <= 0 || N <= 0) return 0;
+    SCN_ARG(x && q && out, "mul_bcast: null operand");
+    hipLaunchKernelGGL(mul_bcast_kernel, dim3(cdiv((long)T * B * N, 256)), dim3(256), 0, st, T, B, N, x, q, out);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
+int reduce_slabs(hipStream_t st, int rows, int N, Slabs s, float* out) {
+    if (rows <= 0 || N <= 0) return 0;
+    SCN_ARG(s.p && out && s.n >= 1, "reduce_slabs: bad argument");
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv((long)rows * N, 256)), dim3(256), 0, st, rows, N, s, out);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
+int transpose2d(hipStream_t st, int R, int C, const float* in, long ldi, float* out, long ldo) {
+    if (R <= 0 || C <= 0) return 0;
+    SCN_ARG(in && out, "transpose2d: null operand");
+    hipLaunchKernelGGL(transpose2d_kernel, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(256), 0, st, R, C, in, ldi, out, ldo);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
+int copy2d(hipStream_t st, int R, int C, const float* in, long ldi, float* out, long ldo) {
+    if (R <= 0 || C <= 0) return 0;
+    SCN_ARG(in && out, "copy2d: null operand");
+    hipLaunchKernelGGL(copy2d_kernel, dim3(cdiv((long)R * C, 256)), dim3(256), 0, st, R, C, in, ldi, out, ldo);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
+int colsum(hipStream_t st, int R, int N, const float* X, long ld, float* out, float beta) {
+    if (N <= 0) return 0;
+    SCN_ARG(X && out && R >= 0, "colsum: bad argument");
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64)), dim3(256), 0, st, R, N, X, ld, out, beta);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
+int gather_rows_tm(hipStream_t st, int B, int T, int L, int M, const long long* caps, const float* table,
+                   int V, float* out_tm) {
+    if (B <= 0 || T <= 0) return 0;
+    SCN_ARG(caps && table && out_tm && T <= L && V > 0, "gather_rows_tm: bad argument");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(B * T), dim3(256), 0, st, B, T, L, M, caps, table, V, out_tm);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
+int scatter_add_rows_tm(hipStream_t st, int B, int T, int L, int M, const long long* caps, const int* dl,
+                        const float* demb_tm, int V, float* dtable) {
+    if (B <= 0 || T <= 0) return 0;
+    SCN_ARG(caps && dl && demb_tm && dtable && T <= L, "scatter_add_rows_tm: bad argument");
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(B * T), dim3(256), 0, st, B, T, L, M, caps, dl, demb_tm, V, dtable);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hidden_to_bm(hipStream_t st, int B, int T, int D, const int* dl, const float* hs_tm,
+                 const float* mask_bm, float* out_bm, float* rowmask) {
+    if (B <= 0 || T <= 0) return 0;
+    SCN_ARG(dl && hs_tm && out_bm, "hidden_to_bm: null operand");
+    hipLaunchKernelGGL(hidden_to_bm_kernel, dim3(B * T), dim3(256), 0, st, B, T, D, dl, hs_tm, mask_bm, out_bm, rowmask);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
+int hidden_from_bm(hipStream_t st, int B, int T, int D, const int* dl, const float* dbm,
+                   const float* mask_bm, float* out_tm) {
+    if (B <= 0 || T <= 0) return 0;
+    SCN_ARG(dl && dbm && out_tm, "hidden_from_bm: null operand");
+    hipLaunchKernelGGL(hidden_from_bm_kernel, dim3(B * T), dim3(256), 0, st, B, T, D, dl, dbm, mask_bm, out_tm);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
+int add_bcast_rows(hipStream_t st, int B, int P, int E, const float* v, float scale, float* x) {
+    if (B <= 0) return 0;
+    SCN_ARG(v && x, "add_bcast_rows: null operand");
+    hipLaunchKernelGGL(add_bcast_rows_kernel, dim3(cdiv((long)B * P * E, 256)), dim3(256), 0, st, B, P, E, v, scale, x);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
+int pool_permute_fwd(hipStream_t st, int B, int C, int Hin, int Win, int Ho, int Wo, const float* x,
+                     long sxb, long sxc, long sxh, long sxw, float* y) {
+    if (B <= 0) return 0;
+    SCN_ARG(x && y && C > 0 && Hin > 0 && Win > 0 && Ho > 0 && Wo > 0, "pool_permute_fwd: bad argument");
+    hipLaunchKernelGGL(pool_permute_fwd_kernel, dim3(B * Ho * Wo), dim3(256), 0, st, B, C, Hin, Win, Ho, Wo, x, sxb,
+                       sxc, sxh, sxw, y);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
+int pool_permute_bwd(hipStream_t st, int B, int C, int Hin, int Win, int Ho, int Wo, const float* dy,
+                     float* dx, long sxb, long sxc, long sxh, long sxw) {
+    if (B <= 0) return 0;
+    SCN_ARG(dy && dx && C > 0 && Hin > 0 && Win > 0 && Ho > 0 && Wo > 0, "pool_permute_bwd: bad argument");
+    hipLaunchKernelGGL(pool_permute_bwd_kernel, dim3(B * Hin * Win), dim3(256), 0, st, B, C, Hin, Win, Ho, Wo, dy, dx,
+                       sxb, sxc, sxh, sxw);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
+int clamp_adam(hipStream_t st, long n, float* p, const float* g, float* m, float* v, double lr, double b1,
+               double b2, double eps, int step, double clip, double gscale) {
+    if (n <= 0) return 0;
+    SCN_ARG(p && g && m && v && step >= 1, "clamp_adam: bad argument");
+    const double bc1 = 1.0 - pow(b1, (double)step);
+    const double sqrt_bc2 = sqrt(1.0 - pow(b2, (double)step));
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(clamp_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n, p, g, m, v, (float)lr, (float)b1,
+                       (float)b2, (float)eps, (float)bc1, (float)sqrt_bc2, (float)clip, (float)gscale);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace scn

@@ -1,0 +1,422 @@
+// Whole-sequence drivers: one C call enqueues every kernel of the teacher-forced decoder forward
+// (models/decoders/attention_scn.py:124-156 / pure_scn.py:114-138) or of its gradient, on the
+// caller's stream.  The time loop lives here, not in Python, so the host cost per timestep is a
+// handful of hipLaunchKernel calls and nothing else.
+//
+// Sequence-level restructuring (algebraically identical to the reference):
+//   * time-invariant projections are hoisted out of the loop: att1 = encoder_att(enc),
+//     qx = s.Wb, qh = s.Hb; the embedding half of u.Wa is batched over all steps (ex), and fc runs
+//     once over all (b,t) rows after the loop;
+//   * in the backward pass the per-step weight-gradient GEMMs collapse into one GEMM per weight over
+//     the stacked (t,b) rows kept in `scratch`, and d att1 / d enc are formed once after the loop.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include "../../include/scnattn.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace scn {
+
+int g_ksplit_scale = 0;  // 0 = auto; >0 forces ksplit for every skinny launch (tuning/testing)
+
+namespace {
+
+struct Carver {
+    float* base;
+    size_t off = 0;  // in floats
+    explicit Carver(float* b) : base(b) {}
+    float* take(size_t n) {
+        float* p = base ? base + off : nullptr;
+        off += (n + 63) & ~size_t(63);  // 256-byte granules keep every buffer 16-byte aligned
+        return p;
+    }
+};
+
+struct Saved {
+    float *att1, *qx, *qh, *ex, *emb_tm, *mean_enc, *Hs, *Cs, *att2_all, *alpha_tm, *awe_all, *gate_all, *z_all,
+        *pa_all, *ph_all, *gates_all, *tanhc_all, *Hd_bm, *rowmask;
+};
+
+struct FwdScratch {
+    float *WcatA, *WD, *slabA, *e, *slabC, *xcat, *slabD;
+};
+
+struct BwdScratch {
+    float *WDb, *WaTz, *WcatT, *dHd_bm, *dhfc_tm, *dr_all, *dpx_all, *dcat_all, *dawe_all, *de_all, *dalpha, *dc,
+        *dqx_acc, *dqh_acc, *sDb, *sZ, *sH, *datt1, *dwpart, *dwtmp, *demb_tm, *dmean, *dh0, *mx_all;
+};
+
+inline size_t sz(long a, long b = 1, long c = 1, long d = 1) { return (size_t)a * b * c * d; }
+
+size_t carve_saved(const scnattn_dims& d, float* base, Saved& s) {
+    Carver c(base);
+    const int B = d.B, P = d.P, E = d.E, A = d.A, D = d.D, F4 = 4 * d.F, T = d.T;
+    s.att1 = d.has_att ? c.take(sz(B, P, A)) : nullptr;
+    s.qx = c.take(sz(B, F4));
+    s.qh = c.take(sz(B, F4));
+    s.ex = c.take(sz(T, B, F4));
+    s.emb_tm = c.take(sz(T, B, d.M));
+    s.mean_enc = c.take(sz(B, E));
+    s.Hs = c.take(sz(T + 1, B, D));
+    s.Cs = c.take(sz(T + 1, B, D));
+    s.att2_all = d.has_att ? c.take(sz(T, B, A)) : nullptr;
+    s.alpha_tm = d.has_att ? c.take(sz(T, B, P)) : nullptr;
+    s.awe_all = d.has_att ? c.take(sz(T, B, E)) : nullptr;
+    s.gate_all = d.has_att ? c.take(sz(T, B, E)) : nullptr;
+    s.z_all = d.has_att ? c.take(sz(T, B, E)) : nullptr;
+    s.pa_all = c.take(sz(T, B, F4));
+    s.ph_all = c.take(sz(T, B, F4));
+    s.gates_all = c.take(sz(T, B, 4 * D));
+    s.tanhc_all = c.take(sz(T, B, D));
+    s.Hd_bm = c.take(sz(B, T, D));
+    s.rowmask = c.take(sz(B, T));
+    return c.off * sizeof(float);
+}
+
+inline int ncatA(const scnattn_dims& d) { return d.has_att ? d.A + d.E + 4 * d.F : 4 * d.F; }
+
+size_t carve_fwd(const scnattn_dims& d, float* base, FwdScratch& s) {
+    Carver c(base);
+    const int B = d.B, D = d.D, F = d.F, NA = ncatA(d);
+    s.WcatA = c.take(sz(D, NA));
+    s.WD = c.take(sz(4, 2 * F, D));
+    s.slabA = c.take(sz(SCN_MAX_KSPLIT, B, NA));
+    s.e = d.has_att ? c.take(sz(B, d.P)) : nullptr;
+    s.slabC = d.has_att ? c.take(sz(SCN_MAX_KSPLIT, B, 4 * F)) : nullptr;
+    s.xcat = c.take(sz(B, 4, 2 * F));
+    s.slabD = c.take(sz(SCN_MAX_KSPLIT, 4, B, D));
+    return c.off * sizeof(float);
+}
+
+size_t carve_bwd(const scnattn_dims& d, float* base, BwdScratch& s) {
+    Carver c(base);
+    const int B = d.B, P = d.P, E = d.E, A = d.A, D = d.D, F = d.F, F4 = 4 * d.F, T = d.T, NC = ncatA(d);
+    s.WDb = c.take(sz(4, D, 2 * F));
+    s.WaTz = d.has_att ? c.take(sz(F4, E)) : nullptr;
+    s.WcatT = c.take(sz(NC, D));
+    s.dHd_bm = c.take(sz(B, T, D));
+    s.dhfc_tm = c.take(sz(T, B, D));
+    s.dr_all = c.take(sz(T, B, 4 * D));
+    s.dpx_all = c.take(sz(T, B, F4));
+    s.dcat_all = c.take(sz(T, B, NC));
+    s.dawe_all = d.has_att ? c.take(sz(T, B, E)) : nullptr;
+    s.de_all = d.has_att ? c.take(sz(T, B, P)) : nullptr;
+    s.dalpha = d.has_att ? c.take(sz(B, P)) : nullptr;
+    s.dc = c.take(sz(B, D));
+    s.dqx_acc = c.take(sz(B, F4));
+    s.dqh_acc = c.take(sz(B, F4));
+    s.sDb = c.take(sz(SCN_MAX_KSPLIT, 4, B, 2 * F));
+    s.sZ = d.has_att ? c.take(sz(SCN_MAX_KSPLIT, B, E)) : nullptr;
+    s.sH = c.take(sz(SCN_MAX_KSPLIT, B, D));
+    s.datt1 = d.has_att ? c.take(sz(B, P, A)) : nullptr;
+    s.dwpart = d.has_att ? c.take(sz(attn_datt1_post_blocks(B, P), A + 1)) : nullptr;
+    s.dwtmp = d.has_att ? c.take(sz(A + 1)) : nullptr;
+    s.demb_tm = c.take(sz(T, B, d.M));
+    s.dmean = c.take(sz(B, E));
+    s.dh0 = c.take(sz(B, D));
+    s.mx_all = c.take(sz(T, B, F4));
+    return c.off * sizeof(float);
+}
+
+int check_dims(const scnattn_dims* d) {
+    SCN_ARG(d, "dims is NULL");
+    SCN_ARG(d->B > 0 && d->P > 0 && d->E > 0 && d->D > 0 && d->F > 0 && d->M > 0 && d->S > 0 && d->V > 0,
+            "dims must be positive");
+    SCN_ARG(d->T > 0 && d->L >= d->T, "need 0 < T <= L");
+    SCN_ARG(!d->has_att || d->A > 0, "attention_dim must be positive");
+    return 0;
+}
+
+int check_bt(const scnattn_dims* d, const int32_t* bt) {
+    SCN_ARG(bt, "bt_host is NULL");
+    for (int t = 0; t < d->T; ++t) {
+        SCN_ARG(bt[t] >= 1 && bt[t] <= d->B, "bt_host[t] must be in [1, B]");
+        SCN_ARG(t == 0 || bt[t] <= bt[t - 1], "bt_host must be non-increasing (captions sorted by length)");
+    }
+    SCN_ARG(bt[0] == d->B, "bt_host[0] must equal B (every caption decodes at least one step)");
+    return 0;
+}
+
+inline int pick(int rows, int N, int K, int groups) {
+    if (g_ksplit_scale > 0) {
+        int ks = g_ksplit_scale;
+        const int kmax = K / 8 > 0 ? K / 8 : 1;
+        if (ks > kmax) ks = kmax;
+        if (ks > SCN_MAX_KSPLIT) ks = SCN_MAX_KSPLIT;
+        return ks;
+    }
+    return skinny_pick_ksplit(rows, N, K, groups);
+}
+
+}  // namespace
+
+int seq_workspace(const scnattn_dims* d, size_t* saved_bytes, size_t* scratch_bytes) {
+    SCN_TRY(check_dims(d));
+    Saved s;
+    FwdScratch f;
+    BwdScratch b;
+    const size_t sv = carve_saved(*d, nullptr, s);
+    const size_t fw = carve_fwd(*d, nullptr, f);
+    const size_t bw = carve_bwd(*d, nullptr, b);
+    if (saved_bytes) *saved_bytes = sv;
+    if (scratch_bytes) *scratch_bytes = fw > bw ? fw : bw;
+    return 0;
+}
+
+int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, const float* enc, const float* tags,
+            const int64_t* caps, const int32_t* dl_dev, const int32_t* bt, const float* drop_mask, float* saved,
+            float* scratch, float* preds, float* alphas) {
+    SCN_TRY(check_dims(dp));
+    SCN_TRY(check_bt(dp, bt));
+    const scnattn_dims& d = *dp;
+    SCN_ARG(w && enc && tags && caps && dl_dev && saved && scratch && preds, "seq_fwd: null argument");
+    SCN_ARG(!d.has_att || alphas, "seq_fwd: alphas is NULL");
+    const int B = d.B, P = d.P, E = d.E, A = d.A, D = d.D, F = d.F, F4 = 4 * F, M = d.M, T = d.T;
+    const int NA = ncatA(d), colph = d.has_att ? A + E : 0;
+    Saved s;
+    FwdScratch f;
+    carve_saved(d, saved, s);
+    carve_fwd(d, scratch, f);
+
+    // ---- weight re-layout: every per-step contraction streams a row-major [K][N] matrix ----------
+    if (d.has_att) {
+        SCN_TRY(transpose2d(st, A, D, w->attention_decoder_att_weight, D, f.WcatA, NA));       // Wd^T
+        SCN_TRY(transpose2d(st, E, D, w->f_beta_weight, D, f.WcatA + A, NA));                  // Wbeta^T
+    }
+    SCN_TRY(copy2d(st, D, F4, w->decode_step_weight_ha, F4, f.WcatA + colph, NA));             // Ha
+    for (int g = 0; g < 4; ++g) {
+        float* wd = f.WD + (long)g * 2 * F * D;
+        SCN_TRY(transpose2d(st, D, F, w->decode_step_weight_ic + g * F, F4, wd, D));           // Wc_g^T
+        SCN_TRY(transpose2d(st, D, F, w->decode_step_weight_hc + g * F, F4, wd + (long)F * D, D));  // Hc_g^T
+    }
+
+    // ---- time-invariant pieces -----------------------------------------------------------------
+    if (d.has_att)
+        SCN_TRY(sgemm(st, false, true, B * P, A, E, 1.f, enc, E, w->attention_encoder_att_weight, E, 0.f, s.att1, A,
+                      w->attention_encoder_att_bias, nullptr, 1, 0, 0, 0));
+    SCN_TRY(sgemm(st, false, false, B, F4, d.S, 1.f, tags, d.S, w->decode_step_weight_ib, F4, 0.f, s.qx, F4, nullptr,
+                  nullptr, 1, 0, 0, 0));
+    SCN_TRY(sgemm(st, false, false, B, F4, d.S, 1.f, tags, d.S, w->decode_step_weight_hb, F4, 0.f, s.qh, F4, nullptr,
+                  nullptr, 1, 0, 0, 0));
+    SCN_TRY(gather_rows_tm(st, B, T, d.L, M, (const long long*)caps, w->embedding_weight, d.V, s.emb_tm));
+    SCN_TRY(sgemm(st, false, false, T * B, F4, M, 1.f, s.emb_tm, M, w->decode_step_weight_ia, F4, 0.f, s.ex, F4,
+                  nullptr, nullptr, 1, 0, 0, 0));
+    SCN_TRY(mean_pixels(st, B, P, E, enc, s.mean_enc));
+    SCN_TRY(sgemm(st, false, true, B, D, E, 1.f, s.mean_enc, E, w->init_h_weight, E, 0.f, s.Hs, D, w->init_h_bias,
+                  nullptr, 1, 0, 0, 0));
+    SCN_TRY(sgemm(st, false, true, B, D, E, 1.f, s.mean_enc, E, w->init_c_weight, E, 0.f, s.Cs, D, w->init_c_bias,
+                  nullptr, 1, 0, 0, 0));
+
+    // ---- the recurrence --------------------------------------------------------------------------
+    const long BD = (long)B * D;
+    for (int t = 0; t < T; ++t) {
+        const int bt_ = bt[t];
+        const float* h = s.Hs + t * BD;
+        const float* c = s.Cs + t * BD;
+        const int ksA = pick(bt_, NA, D, 1);
+        SCN_TRY(skinny_gemm(st, bt_, NA, D, 1, h, D, 0, f.WcatA, NA, 0, f.slabA, NA, 0, (long)B * NA, ksA));
+        Slabs pz{nullptr, 0, 0, 0};
+        if (d.has_att) {
+            SCN_TRY(attn_scores(st, bt_, P, A, s.att1, Slabs{f.slabA, ksA, (long)B * NA, NA},
+                                w->attention_decoder_att_bias, w->attention_full_att_weight,
+                                w->attention_full_att_bias, f.e, s.att2_all + (long)t * B * A));
+            SCN_TRY(attn_context(st, bt_, P, E, enc, f.e, Slabs{f.slabA + A, ksA, (long)B * NA, NA}, w->f_beta_bias,
+                                 alphas + (long)t * P, (long)T * P, s.alpha_tm + (long)t * B * P,
+                                 s.awe_all + (long)t * B * E, s.gate_all + (long)t * B * E, s.z_all + (long)t * B * E));
+            const int ksC = pick(bt_, F4, E, 1);
+            SCN_TRY(skinny_gemm(st, bt_, F4, E, 1, s.z_all + (long)t * B * E, E, 0,
+                                w->decode_step_weight_ia + (long)M * F4, F4, 0, f.slabC, F4, 0, (long)B * F4, ksC));
+            pz = Slabs{f.slabC, ksC, (long)B * F4, F4};
+        }
+        SCN_TRY(scn_mix_fwd(st, bt_, F4, pz, s.ex + (long)t * B * F4, Slabs{f.slabA + colph, ksA, (long)B * NA, NA},
+                            s.qx, s.qh, s.pa_all + (long)t * B * F4, s.ph_all + (long)t * B * F4, f.xcat));
+        const int ksD = pick(bt_, D, 2 * F, 4);
+        SCN_TRY(skinny_gemm(st, bt_, D, 2 * F, 4, f.xcat, 8 * F, 2 * F, f.WD, D, (long)2 * F * D, f.slabD, D, BD,
+                            4 * BD, ksD));
+        SCN_TRY(lstm_fwd(st, bt_, D, Slabs{f.slabD, ksD, 4 * BD, D}, BD, w->decode_step_bias_ih, w->decode_step_bias_hh,
+                         c, s.gates_all + (long)t * B * 4 * D, s.Cs + (t + 1) * BD, s.Hs + (t + 1) * BD,
+                         s.tanhc_all + t * BD));
+    }
+
+    // ---- dropout + fc over all (b,t) rows at once ------------------------------------------------
+    SCN_TRY(hidden_to_bm(st, B, T, D, dl_dev, s.Hs + BD, drop_mask, s.Hd_bm, s.rowmask));
+    SCN_TRY(sgemm(st, false, true, B * T, d.V, D, 1.f, s.Hd_bm, D, w->fc_weight, D, 0.f, preds, d.V, w->fc_bias,
+                  s.rowmask, 1, 0, 0, 0));
+    return 0;
+}
+
+int seq_bwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, const float* enc, const float* tags,
+            const int64_t* caps, const int32_t* dl_dev, const int32_t* bt, const float* drop_mask, const float* saved,
+            float* scratch, const float* dpreds, const float* dalphas, const scnattn_params* g, float* denc,
+            float* dtags) {
+    SCN_TRY(check_dims(dp));
+    SCN_TRY(check_bt(dp, bt));
+    const scnattn_dims& d = *dp;
+    SCN_ARG(w && g && enc && tags && caps && dl_dev && saved && scratch && dpreds, "seq_bwd: null argument");
+    const int B = d.B, P = d.P, E = d.E, A = d.A, D = d.D, F = d.F, F4 = 4 * F, M = d.M, T = d.T, V = d.V;
+    const int NC = ncatA(d);  // columns of the concatenated [dph | dgpre | datt2] operand
+    const int TB = T * B;
+    const long BD = (long)B * D;
+    Saved s;
+    BwdScratch k;
+    carve_saved(d, const_cast<float*>(saved), s);
+    carve_bwd(d, scratch, k);
+
+    // ---- fc / dropout ----------------------------------------------------------------------------
+    SCN_TRY(sgemm(st, false, false, B * T, D, V, 1.f, dpreds, V, w->fc_weight, D, 0.f, k.dHd_bm, D, nullptr, nullptr, 1,
+                  0, 0, 0));
+    if (g->fc_weight)
+        SCN_TRY(sgemm(st, true, false, V, D, B * T, 1.f, dpreds, V, s.Hd_bm, D, 0.f, g->fc_weight, D, nullptr, nullptr,
+                      1, 0, 0, 0));
+    if (g->fc_bias)  // only rows that were decoded carry the bias
+        SCN_TRY(sgemm(st, false, false, 1, V, B * T, 1.f, s.rowmask, B * T, dpreds, V, 0.f, g->fc_bias, V, nullptr,
+                      nullptr, 1, 0, 0, 0));
+    SCN_TRY(hidden_from_bm(st, B, T, D, dl_dev, k.dHd_bm, drop_mask, k.dhfc_tm));
+
+    // ---- transposed weight layouts for the backward contractions ------------------------------------
+    for (int gi = 0; gi < 4; ++gi) {
+        float* wd = k.WDb + (long)gi * D * 2 * F;
+        SCN_TRY(copy2d(st, D, F, w->decode_step_weight_ic + gi * F, F4, wd, 2 * F));
+        SCN_TRY(copy2d(st, D, F, w->decode_step_weight_hc + gi * F, F4, wd + F, 2 * F));
+    }
+    SCN_TRY(transpose2d(st, D, F4, w->decode_step_weight_ha, F4, k.WcatT, D));  // Ha^T : [4F][D]
+    if (d.has_att) {
+        SCN_TRY(transpose2d(st, E, F4, w->decode_step_weight_ia + (long)M * F4, F4, k.WaTz, E));  // Wa[M:]^T
+        SCN_TRY(copy2d(st, E, D, w->f_beta_weight, D, k.WcatT + (long)F4 * D, D));
+        SCN_TRY(copy2d(st, A, D, w->attention_decoder_att_weight, D, k.WcatT + (long)(F4 + E) * D, D));
+    }
+    SCN_HIP(hipMemsetAsync(k.dc, 0, sizeof(float) * BD, st));
+    SCN_HIP(hipMemsetAsync(k.dqx_acc, 0, sizeof(float) * B * F4, st));
+    SCN_HIP(hipMemsetAsync(k.dqh_acc, 0, sizeof(float) * B * F4, st));
+
+    // ---- reverse recurrence ----------------------------------------------------------------------
+    int ksH = 0;
+    for (int t = T - 1; t >= 0; --t) {
+        const int bt_ = bt[t];
+        const int btn = (t + 1 < T) ? bt[t + 1] : 0;
+        float* dr = k.dr_all + (long)t * B * 4 * D;
+        float* dcat = k.dcat_all + (long)t * B * NC;
+        float* dpx = k.dpx_all + (long)t * B * F4;
+        SCN_TRY(lstm_bwd(st, bt_, btn, D, k.dhfc_tm + t * BD,
+                         (t + 1 < T) ? Slabs{k.sH, ksH, BD, D} : Slabs{nullptr, 0, 0, 0}, k.dc,
+                         s.gates_all + (long)t * B * 4 * D, s.Cs + t * BD, s.tanhc_all + t * BD, dr));
+        const int ksDb = pick(bt_, 2 * F, D, 4);
+        SCN_TRY(skinny_gemm(st, bt_, 2 * F, D, 4, dr, 4 * D, D, k.WDb, 2 * F, (long)D * 2 * F, k.sDb, 2 * F,
+                            (long)B * 2 * F, (long)4 * B * 2 * F, ksDb));
+        SCN_TRY(scn_mix_bwd(st, bt_, F4, Slabs{k.sDb, ksDb, (long)4 * B * 2 * F, 2 * F}, (long)B * 2 * F, s.qx, s.qh,
+                            s.pa_all + (long)t * B * F4, s.ph_all + (long)t * B * F4, dpx, dcat, NC, k.dqx_acc,
+                            k.dqh_acc));
+        if (d.has_att) {
+            const int ksZ = pick(bt_, E, F4, 1);
+            SCN_TRY(skinny_gemm(st, bt_, E, F4, 1, dpx, F4, 0, k.WaTz, E, 0, k.sZ, E, 0, (long)B * E, ksZ));
+            float* dawe = k.dawe_all + (long)t * B * E;
+            SCN_TRY(gate_bwd(st, bt_, E, Slabs{k.sZ, ksZ, (long)B * E, E}, s.awe_all + (long)t * B * E,
+                             s.gate_all + (long)t * B * E, dawe, dcat + F4, NC));
+            SCN_TRY(attn_dalpha(st, bt_, P, E, enc, dawe, dalphas ? dalphas + (long)t * P : nullptr, (long)T * P,
+                                k.dalpha));
+            SCN_TRY(attn_softmax_bwd(st, bt_, P, A, s.att1, s.att2_all + (long)t * B * A, w->attention_full_att_weight,
+                                     s.alpha_tm + (long)t * B * P, k.dalpha, k.de_all + (long)t * B * P,
+                                     dcat + F4 + E, NC));
+        }
+        ksH = pick(bt_, D, NC, 1);
+        SCN_TRY(skinny_gemm(st, bt_, D, NC, 1, dcat, NC, 0, k.WcatT, D, 0, k.sH, D, 0, BD, ksH));
+    }
+    SCN_TRY(reduce_slabs(st, B, D, Slabs{k.sH, ksH, BD, D}, k.dh0));  // d loss / d h0; d/d c0 is k.dc
+
+    // ---- weight gradients: one GEMM per weight over the stacked (t,b) rows ---------------------------
+    if (g->decode_step_weight_ia) {
+        SCN_TRY(sgemm(st, true, false, M, F4, TB, 1.f, s.emb_tm, M, k.dpx_all, F4, 0.f, g->decode_step_weight_ia, F4,
+                      nullptr, nullptr, 1, 0, 0, 0));
+        if (d.has_att)
+            SCN_TRY(sgemm(st, true, false, E, F4, TB, 1.f, s.z_all, E, k.dpx_all, F4, 0.f,
+                          g->decode_step_weight_ia + (long)M * F4, F4, nullptr, nullptr, 1, 0, 0, 0));
+    }
+    if (g->embedding_weight) {
+        SCN_TRY(sgemm(st, false, true, TB, M, F4, 1.f, k.dpx_all, F4, w->decode_step_weight_ia, F4, 0.f, k.demb_tm, M,
+                      nullptr, nullptr, 1, 0, 0, 0));
+        SCN_TRY(scatter_add_rows_tm(st, B, T, d.L, M, (const long long*)caps, dl_dev, k.demb_tm, V,
+                                    g->embedding_weight));
+    }
+    if (g->decode_step_weight_ic) {
+        SCN_TRY(mul_bcast(st, T, B, F4, s.pa_all, s.qx, k.mx_all));
+        SCN_TRY(sgemm(st, true, false, D, F, TB, 1.f, k.dr_all, 4 * D, k.mx_all, F4, 0.f, g->decode_step_weight_ic, F4,
+                      nullptr, nullptr, 4, D, F, F));
+    }
+    if (g->decode_step_weight_hc) {
+        SCN_TRY(mul_bcast(st, T, B, F4, s.ph_all, s.qh, k.mx_all));
+        SCN_TRY(sgemm(st, true, false, D, F, TB, 1.f, k.dr_all, 4 * D, k.mx_all, F4, 0.f, g->decode_step_weight_hc, F4,
+                      nullptr, nullptr, 4, D, F, F));
+    }
+    if (g->decode_step_weight_ha)
+        SCN_TRY(sgemm(st, true, false, D, F4, TB, 1.f, s.Hs, D, k.dcat_all, NC, 0.f, g->decode_step_weight_ha, F4,
+                      nullptr, nullptr, 1, 0, 0, 0));
+    if (g->decode_step_weight_ib)
+        SCN_TRY(sgemm(st, true, false, d.S, F4, B, 1.f, tags, d.S, k.dqx_acc, F4, 0.f, g->decode_step_weight_ib, F4,
+                      nullptr, nullptr, 1, 0, 0, 0));
+    if (g->decode_step_weight_hb)
+        SCN_TRY(sgemm(st, true, false, d.S, F4, B, 1.f, tags, d.S, k.dqh_acc, F4, 0.f, g->decode_step_weight_hb, F4,
+                      nullptr, nullptr, 1, 0, 0, 0));
+    if (dtags) {
+        SCN_TRY(sgemm(st, false, true, B, d.S, F4, 1.f, k.dqx_acc, F4, w->decode_step_weight_ib, F4, 0.f, dtags, d.S,
+                      nullptr, nullptr, 1, 0, 0, 0));
+        SCN_TRY(sgemm(st, false, true, B, d.S, F4, 1.f, k.dqh_acc, F4, w->decode_step_weight_hb, F4, 1.f, dtags, d.S,
+                      nullptr, nullptr, 1, 0, 0, 0));
+    }
+    if (g->decode_step_bias_ih) SCN_TRY(colsum(st, TB, 4 * D, k.dr_all, 4 * D, g->decode_step_bias_ih, 0.f));
+    if (g->decode_step_bias_hh) SCN_TRY(colsum(st, TB, 4 * D, k.dr_all, 4 * D, g->decode_step_bias_hh, 0.f));
+
+    if (d.has_att) {
+        if (g->f_beta_weight)
+            SCN_TRY(sgemm(st, true, false, E, D, TB, 1.f, k.dcat_all + F4, NC, s.Hs, D, 0.f, g->f_beta_weight, D,
+                          nullptr, nullptr, 1, 0, 0, 0));
+        if (g->f_beta_bias) SCN_TRY(colsum(st, TB, E, k.dcat_all + F4, NC, g->f_beta_bias, 0.f));
+        if (g->attention_decoder_att_weight)
+            SCN_TRY(sgemm(st, true, false, A, D, TB, 1.f, k.dcat_all + F4 + E, NC, s.Hs, D, 0.f,
+                          g->attention_decoder_att_weight, D, nullptr, nullptr, 1, 0, 0, 0));
+        if (g->attention_decoder_att_bias)
+            SCN_TRY(colsum(st, TB, A, k.dcat_all + F4 + E, NC, g->attention_decoder_att_bias, 0.f));
+        int nblk = 0;
+        SCN_TRY(attn_datt1_post(st, B, P, A, T, dl_dev, s.att1, s.att2_all, k.de_all, w->attention_full_att_weight,
+                                k.datt1, k.dwpart, &nblk));
+        SCN_TRY(colsum(st, nblk, A + 1, k.dwpart, A + 1, k.dwtmp, 0.f));
+        if (g->attention_full_att_weight)
+            SCN_TRY(copy2d(st, 1, A, k.dwtmp, A + 1, g->attention_full_att_weight, A));
+        if (g->attention_full_att_bias) SCN_TRY(copy2d(st, 1, 1, k.dwtmp + A, 1, g->attention_full_att_bias, 1));
+        if (g->attention_encoder_att_weight)
+            SCN_TRY(sgemm(st, true, false, A, E, B * P, 1.f, k.datt1, A, enc, E, 0.f, g->attention_encoder_att_weight,
+                          E, nullptr, nullptr, 1, 0, 0, 0));
+        if (g->attention_encoder_att_bias)
+            SCN_TRY(colsum(st, B * P, A, k.datt1, A, g->attention_encoder_att_bias, 0.f));
+    }
+
+    // ---- initial state (attention_scn.py:82-93) -----------------------------------------------------
+    if (g->init_h_weight)
+        SCN_TRY(sgemm(st, true, false, D, E, B, 1.f, k.dh0, D, s.mean_enc, E, 0.f, g->init_h_weight, E, nullptr,
+                      nullptr, 1, 0, 0, 0));
+    if (g->init_h_bias) SCN_TRY(colsum(st, B, D, k.dh0, D, g->init_h_bias, 0.f));
+    if (g->init_c_weight)
+        SCN_TRY(sgemm(st, true, false, D, E, B, 1.f, k.dc, D, s.mean_enc, E, 0.f, g->init_c_weight, E, nullptr, nullptr,
+                      1, 0, 0, 0));
+    if (g->init_c_bias) SCN_TRY(colsum(st, B, D, k.dc, D, g->init_c_bias, 0.f));
+
+    // ---- d loss / d encoder_out (only when the encoder is fine-tuned) -------------------------------
+    if (denc) {
+        if (d.has_att) {
+            SCN_TRY(sgemm(st, false, false, B * P, E, A, 1.f, k.datt1, A, w->attention_encoder_att_weight, E, 0.f,
+                          denc, E, nullptr, nullptr, 1, 0, 0, 0));
+            // denc[b] += alpha_b^T (P x T) . dawe_b (T x E), batched over b
+            SCN_TRY(sgemm(st, true, false, P, E, T, 1.f, s.alpha_tm, (long)B * P, k.dawe_all, (long)B * E, 1.f, denc, E,
+                          nullptr, nullptr, B, P, E, (long)P * E));
+        } else {
+            SCN_HIP(hipMemsetAsync(denc, 0, sizeof(float) * B * P * E, st));
+        }
+        SCN_TRY(sgemm(st, false, false, B, E, D, 1.f, k.dh0, D, w->init_h_weight, E, 0.f, k.dmean, E, nullptr, nullptr,
+                      1, 0, 0, 0));
+        SCN_TRY(sgemm(st, false, false, B, E, D, 1.f, k.dc, D, w->init_c_weight, E, 1.f, k.dmean, E, nullptr, nullptr,
+                      1, 0, 0, 0));
+        SCN_TRY(add_bcast_rows(st, B, P, E, k.dmean, 1.f / (float)P, denc));
+    }
+    return 0;
+}
+
+}  // namespace scn

@@ -1,0 +1,124 @@
+"""Logic shared by the three caption decoders (the reference repeats it in each file):
+length sort + permutation (attention_scn.py:115-131), the dropout mask that sits between h and fc
+(:154), and beam search (:160-296)."""
+import torch
+import torch.nn.functional as F
+
+from scnattn import functional as SF
+from utils.token import start_token, end_token
+
+
+def sort_by_length(encoder_out, encoded_captions, caption_lengths, sort_ind=None):
+    """Flatten pixels, sort rows by caption length (descending) and permute images + captions.
+    Tags are deliberately NOT touched (the reference indexes the un-permuted tags, :152).
+    Returns enc (B,P,E), caps (B,L), decode_lengths (list[int]), sort_ind."""
+    B, E = encoder_out.size(0), encoder_out.size(-1)
+    enc = encoder_out.reshape(B, -1, E)
+    lens = caption_lengths.squeeze(1)
+    if sort_ind is None:
+        lens, sort_ind = lens.sort(dim=0, descending=True, stable=True)
+    else:
+        lens = lens[sort_ind]
+    enc = enc[sort_ind]
+    caps = encoded_captions[sort_ind]
+    decode_lengths = (lens - 1).tolist()  # the one host sync of the forward pass, as in the reference
+    return enc, caps, decode_lengths, (lens - 1).to(torch.int32), sort_ind
+
+
+def active_rows(decode_lengths):
+    return [sum(l > t for l in decode_lengths) for t in range(max(decode_lengths))]
+
+
+def make_drop_mask(module, B, T, D, device):
+    """Pre-scaled Bernoulli mask for fc(dropout(h)) or None (eval mode / p == 0).  A test can pin the
+    mask by setting ``module.drop_mask_override`` (B,T,D)."""
+    override = getattr(module, "drop_mask_override", None)
+    if override is not None:
+        return override.to(device=device, dtype=torch.float32)
+    p = module.dropout.p
+    if not module.training or p <= 0.0:
+        return None
+    keep = 1.0 - p
+    return torch.empty((B, T, D), device=device, dtype=torch.float32).bernoulli_(keep).div_(keep)
+
+
+def beam_search(decoder, beam_size, word_map, encoder_out, tag_out, use_attention, use_tags):
+    """Beam search shared by AttentionSCN / PureSCN / PureAttention ``sample`` (reference
+    attention_scn.py:160-296, pure_scn.py:142-249, pure_attention.py:153-281).  Identical control flow,
+    with the unrolled-index split done by FLOOR division (the reference's ``/`` breaks on torch >= 1.5)."""
+    k = beam_size
+    vocab_size = len(word_map)
+    dev = encoder_out.device
+    enc_image_size = encoder_out.size(1)
+    encoder_dim = encoder_out.size(3)
+    encoder_out = encoder_out.reshape(1, -1, encoder_dim)
+    num_pixels = encoder_out.size(1)
+    encoder_out = encoder_out.expand(k, num_pixels, encoder_dim).contiguous()
+    tags = tag_out.expand(k, tag_out.size(1)).contiguous() if use_tags else None
+
+    k_prev_words = torch.full((k, 1), word_map[start_token], dtype=torch.long, device=dev)
+    seqs = k_prev_words
+    top_k_scores = torch.zeros(k, 1, device=dev)
+    seqs_alpha = torch.ones(k, 1, enc_image_size, enc_image_size, device=dev)
+    complete_seqs, complete_seqs_alpha, complete_seqs_scores = [], [], []
+    step = 1
+    h, c = decoder.init_hidden_state(encoder_out)
+    while True:
+        embeddings = decoder.embedding(k_prev_words).squeeze(1)
+        if use_attention:
+            awe, alpha = decoder.attention(encoder_out, h)
+            alpha = alpha.view(-1, enc_image_size, enc_image_size)
+            gate = torch.sigmoid(SF.linear(h, decoder.f_beta.weight, decoder.f_beta.bias))
+            step_in = torch.cat([embeddings, gate * awe], dim=1)
+        else:
+            alpha = None
+            step_in = embeddings
+        if use_tags:
+            h, c = decoder.decode_step(step_in, tags, (h, c))
+        else:
+            h, c = decoder.decode_step(step_in, (h, c))
+        scores = F.log_softmax(SF.linear(h, decoder.fc.weight, decoder.fc.bias), dim=1)
+        scores = top_k_scores.expand_as(scores) + scores
+        if step == 1:
+            top_k_scores, top_k_words = scores[0].topk(k, 0, True, True)
+        else:
+            top_k_scores, top_k_words = scores.view(-1).topk(k, 0, True, True)
+        prev_word_inds = torch.div(top_k_words, vocab_size, rounding_mode='floor')
+        next_word_inds = top_k_words % vocab_size
+        seqs = torch.cat([seqs[prev_word_inds], next_word_inds.unsqueeze(1)], dim=1)
+        if use_attention:
+            seqs_alpha = torch.cat([seqs_alpha[prev_word_inds], alpha[prev_word_inds].unsqueeze(1)], dim=1)
+        nxt = next_word_inds.tolist()
+        incomplete_inds = [i for i, w in enumerate(nxt) if w != word_map[end_token]]
+        complete_inds = sorted(set(range(len(nxt))) - set(incomplete_inds))
+        if complete_inds:
+            complete_seqs.extend(seqs[complete_inds].tolist())
+            if use_attention:
+                complete_seqs_alpha.extend(seqs_alpha[complete_inds].tolist())
+            complete_seqs_scores.extend(top_k_scores[complete_inds].tolist())
+        k -= len(complete_inds)
+        if k == 0:
+            break
+        seqs = seqs[incomplete_inds]
+        if use_attention:
+            seqs_alpha = seqs_alpha[incomplete_inds]
+        keep = prev_word_inds[incomplete_inds]
+        h, c = h[keep], c[keep]
+        encoder_out = encoder_out[keep]
+        if use_tags:
+            tags = tags[keep]
+        top_k_scores = top_k_scores[incomplete_inds].unsqueeze(1)
+        k_prev_words = next_word_inds[incomplete_inds].unsqueeze(1)
+        if step > 50:
+            break
+        step += 1
+    if not complete_seqs_scores:  # nothing reached <end> within 50 steps: fall back to the best open beam
+        complete_seqs = seqs.tolist()
+        complete_seqs_scores = top_k_scores.view(-1).tolist()
+        if use_attention:
+            complete_seqs_alpha = seqs_alpha.tolist()
+    i = complete_seqs_scores.index(max(complete_seqs_scores))
+    seq = complete_seqs[i]
+    if use_attention:
+        return seq, complete_seqs_alpha[i]
+    return seq

@@ -1,0 +1,70 @@
+"""ResNet-152 trunk (v1.5: stride on the 3x3 conv) built from plain torch.nn layers, laid out so that
+the module tree -- and therefore every state_dict key -- equals
+``nn.Sequential(*list(torchvision.models.resnet152().children())[:-2])`` as used by the reference
+(models/encoders/caption.py:17-22): children 0..7 = conv1, bn1, relu, maxpool, layer1..layer4.
+
+torchvision is not installed in this image (nor on the GPU box), and the reference's
+``pretrained=True`` needs a download, so weights are random-init by torchvision's own recipe
+(kaiming-normal fan-out convs, BN gamma=1 beta=0) unless a state_dict is loaded.  On MI355X the
+convolutions run on MIOpen's MFMA kernels through PyTorch-ROCm; channels-last memory format is used so
+the 1x1 convolutions are plain GEMMs over contiguous channels."""
+import torch
+from torch import nn
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * self.expansion, kernel_size=1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * self.expansion)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        identity = x
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        return self.relu(out + identity)
+
+
+def _make_layer(inplanes, planes, blocks, stride):
+    downsample = None
+    if stride != 1 or inplanes != planes * Bottleneck.expansion:
+        downsample = nn.Sequential(
+            nn.Conv2d(inplanes, planes * Bottleneck.expansion, kernel_size=1, stride=stride, bias=False),
+            nn.BatchNorm2d(planes * Bottleneck.expansion))
+    layers = [Bottleneck(inplanes, planes, stride, downsample)]
+    inplanes = planes * Bottleneck.expansion
+    for _ in range(1, blocks):
+        layers.append(Bottleneck(inplanes, planes))
+    return nn.Sequential(*layers), inplanes
+
+
+def resnet152_trunk(depths=(3, 8, 36, 3), keep_avgpool=False):
+    """conv1 .. layer4 (optionally + global average pool, for the tagger) as one nn.Sequential."""
+    mods = [nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False), nn.BatchNorm2d(64),
+            nn.ReLU(inplace=True), nn.MaxPool2d(kernel_size=3, stride=2, padding=1)]
+    inplanes = 64
+    for planes, blocks, stride in zip((64, 128, 256, 512), depths, (1, 2, 2, 2)):
+        layer, inplanes = _make_layer(inplanes, planes, blocks, stride)
+        mods.append(layer)
+    if keep_avgpool:
+        mods.append(nn.AdaptiveAvgPool2d((1, 1)))
+    trunk = nn.Sequential(*mods)
+    for m in trunk.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        elif isinstance(m, nn.BatchNorm2d):
+            nn.init.constant_(m.weight, 1)
+            nn.init.constant_(m.bias, 0)
+    return trunk

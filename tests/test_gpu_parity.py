@@ -1,0 +1,317 @@
+"""GPU parity tests (run on the MI355X box with ``-m gpu``): every HIP kernel / driver of libscnattn
+against the CPU oracle (oracle/scnattn_ref.py) and against the committed golden vectors that were
+produced by the reference's own modules.  All calls go through the C ABI (ctypes).
+
+Tolerance: north_star asks for outputs within 1e-4 rel-err of the CPU reference in fp32; we use
+rel_err = max|a-b| / max|b| <= 1e-4 for outputs and <= 2e-4 for gradients (sums over up to 51 steps
+with a different, but fixed, reduction order)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden, params_from, t, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL_OUT = 1e-4
+TOL_GRAD = 2e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from scnattn import _lib
+    _lib.lib()  # must load: there is no fallback
+    return torch.device("cuda:0")
+
+
+def _ok(a, b, tol, what=""):
+    e = rel_err(a, b)
+    assert e <= tol, "%s rel_err %.3e > %.1e" % (what, e, tol)
+    return e
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (37, 53, 29), (300, 130, 257), (1, 700, 96), (196, 512, 2048)])
+def test_sgemm(dev, ta, tb, M, N, K):
+    from scnattn import functional as SF
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + ta * 2 + tb)
+    a = torch.randn((K, M) if ta else (M, K), generator=g)
+    b = torch.randn((N, K) if tb else (K, N), generator=g)
+    bias = torch.randn(N, generator=g)
+    c0 = torch.randn(M, N, generator=g)
+    ref = (a.double().t() if ta else a.double()) @ (b.double().t() if tb else b.double())
+    out = SF.gemm(a.to(dev), b.to(dev), ta=bool(ta), tb=bool(tb))
+    _ok(out, ref, 2e-6, "gemm")
+    out2 = c0.to(dev).clone()
+    SF.gemm(a.to(dev), b.to(dev), ta=bool(ta), tb=bool(tb), bias=bias.to(dev), out=out2, beta=0.5, alpha=2.0)
+    _ok(out2, 2.0 * ref + 0.5 * c0.double() + bias.double(), 2e-6, "gemm epilogue")
+    mask = (torch.arange(M) % 3 != 0).float()
+    out3 = SF.gemm(a.to(dev), b.to(dev), ta=bool(ta), tb=bool(tb), bias=bias.to(dev), rowmask=mask.to(dev))
+    _ok(out3, (ref + bias.double()) * mask.double()[:, None], 2e-6, "gemm rowmask")
+    assert out3[0].abs().max().item() == 0.0
+
+
+def test_sgemm_batched_strided(dev):
+    from scnattn import functional as SF
+    g = torch.Generator().manual_seed(5)
+    B, Pn, T, E = 5, 9, 7, 12
+    alpha = torch.randn(T, B, Pn, generator=g)
+    dawe = torch.randn(T, B, E, generator=g)
+    out = torch.zeros(B, Pn, E).to(dev)
+    SF.gemm(alpha.to(dev), dawe.to(dev), ta=True, out=out, M=Pn, N=E, K=T, lda=B * Pn, ldb=B * E, ldc=E,
+            batch=B, sa=Pn, sb=E, sc=Pn * E)
+    ref = torch.einsum("tbp,tbe->bpe", alpha.double(), dawe.double())
+    _ok(out, ref, 2e-6)
+
+
+@pytest.mark.parametrize("rows,N,K,groups,ks", [(32, 128, 512, 1, 0), (32, 2048, 2048, 1, 0), (7, 45, 77, 1, 3),
+                                                (32, 512, 1024, 4, 0), (5, 36, 40, 4, 2), (1, 33, 9, 1, 1),
+                                                (40, 64, 128, 1, 2), (32, 4608, 512, 1, 4), (32, 512, 4608, 1, 16)])
+def test_skinny_gemm(dev, rows, N, K, groups, ks):
+    import ctypes as C
+    from scnattn._lib import call, ptr, stream_of
+    g = torch.Generator().manual_seed(rows + N + K)
+    X = torch.randn(rows, groups * K, generator=g)
+    W = torch.randn(groups, K, N, generator=g)
+    Xd, Wd = X.to(dev), W.to(dev)
+    Y = torch.full((16, groups, rows, N), float("nan"), device=dev)
+    used = C.c_int(0)
+    call("scnattn_skinny_gemm", stream_of(Xd), rows, N, K, groups, ptr(Xd), groups * K, K, ptr(Wd), N, K * N,
+         ptr(Y), N, rows * N, groups * rows * N, ks, C.byref(used))
+    out = Y[:used.value].sum(0)
+    ref = torch.einsum("rgk,gkn->grn", X.view(rows, groups, K).double(), W.double())
+    _ok(out, ref, 3e-6, "skinny ks=%d" % used.value)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_attention_module_golden(dev):
+    from models.attention import Attention
+    d = load_golden("attention")
+    E, A = d["p.encoder_att.weight"].shape[1], d["p.encoder_att.weight"].shape[0]
+    D = d["p.decoder_att.weight"].shape[1]
+    m = Attention(E, D, A).to(dev)
+    m.load_state_dict(params_from(d))
+    enc, h = t(d["enc"]).to(dev).requires_grad_(True), t(d["h"]).to(dev).requires_grad_(True)
+    awe, alpha = m(enc, h)
+    _ok(awe, d["awe"], TOL_OUT, "awe"); _ok(alpha, d["alpha"], TOL_OUT, "alpha")
+    ((awe * t(d["w_awe"]).to(dev)).sum() + (alpha * t(d["w_alpha"]).to(dev)).sum()).backward()
+    _ok(enc.grad, d["denc"], TOL_GRAD, "denc"); _ok(h.grad, d["dh"], TOL_GRAD, "dh")
+    for k, p in m.named_parameters():
+        _ok(p.grad, d["g." + k], TOL_GRAD, k)
+
+
+def test_attention_module_full_size(dev):
+    from models.attention import Attention
+    from oracle import scnattn_ref as R
+    torch.manual_seed(3)
+    B, Pn, E, D, A = 8, 196, 2048, 512, 512
+    m = Attention(E, D, A)
+    enc, h = torch.rand(B, Pn, E), torch.randn(B, D) * 0.5
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    e1, h1 = enc.clone().requires_grad_(True), h.clone().requires_grad_(True)
+    awe_r, al_r = R.attention_forward(P, "", e1, h1)
+    wa, wl = torch.randn(B, E), torch.randn(B, Pn)
+    ((awe_r * wa).sum() + (al_r * wl).sum()).backward()
+    m = m.to(dev)
+    e2, h2 = enc.to(dev).requires_grad_(True), h.to(dev).requires_grad_(True)
+    awe, al = m(e2, h2)
+    _ok(awe, awe_r, TOL_OUT, "awe"); _ok(al, al_r, TOL_OUT, "alpha")
+    assert abs(al.sum(1).max().item() - 1.0) < 1e-5
+    ((awe * wa.to(dev)).sum() + (al * wl.to(dev)).sum()).backward()
+    _ok(e2.grad, e1.grad, TOL_GRAD, "denc"); _ok(h2.grad, h1.grad, TOL_GRAD, "dh")
+    for k, p in m.named_parameters():
+        _ok(p.grad, P[k].grad, TOL_GRAD, k)
+
+
+def test_scn_cell_module_golden(dev):
+    from models.scn_cell import SCNCell
+    d = load_golden("scn_cell")
+    I, F4 = d["p.weight_ia"].shape
+    S, H = d["p.weight_ib"].shape[0], d["p.weight_ic"].shape[0]
+    m = SCNCell(I, H, S, F4 // 4).to(dev)
+    m.load_state_dict(params_from(d))
+    assert repr(m) == str(d["repr"])
+    u, s = t(d["u"]).to(dev).requires_grad_(True), t(d["s"]).to(dev).requires_grad_(True)
+    h0, c0 = t(d["h0"]).to(dev).requires_grad_(True), t(d["c0"]).to(dev).requires_grad_(True)
+    h, c = m(u, s, (h0, c0))
+    _ok(h, d["h"], TOL_OUT, "h"); _ok(c, d["c"], TOL_OUT, "c")
+    ((h * t(d["wh"]).to(dev)).sum() + (c * t(d["wc"]).to(dev)).sum()).backward()
+    _ok(u.grad, d["du"], TOL_GRAD, "du"); _ok(s.grad, d["ds"], TOL_GRAD, "ds")
+    _ok(h0.grad, d["dh0"], TOL_GRAD, "dh0"); _ok(c0.grad, d["dc0"], TOL_GRAD, "dc0")
+    for k, p in m.named_parameters():
+        _ok(p.grad, d["g." + k], TOL_GRAD, k)
+    h2, c2 = m(u.detach(), s.detach())  # hx=None -> zeros
+    _ok(h2, d["h_none"], TOL_OUT); _ok(c2, d["c_none"], TOL_OUT)
+    msgs = [str(x) for x in d["errors"]]
+    B = u.shape[0]
+    with pytest.raises(RuntimeError) as ei:
+        m(torch.randn(B, I + 1, device=dev), s.detach())
+    assert str(ei.value) == msgs[0]
+    with pytest.raises(RuntimeError) as ei:
+        m(u.detach(), s.detach(), (torch.randn(B + 1, H, device=dev), torch.randn(B + 1, H, device=dev)))
+    assert str(ei.value) == msgs[1]
+    with pytest.raises(RuntimeError) as ei:
+        m(u.detach(), s.detach(), (torch.randn(B, H + 1, device=dev), torch.randn(B, H + 1, device=dev)))
+    assert str(ei.value) == msgs[2]
+
+
+# ------------------------------------------------------------------------------------------------
+def _build_decoder(kind, d, dev):
+    from models.decoders.attention_scn import AttentionSCN
+    from models.decoders.pure_scn import PureSCN
+    from models.decoders.pure_attention import PureAttention
+    V, M = d["p.embedding.weight"].shape
+    D, E = d["p.init_h.weight"].shape
+    if kind == "pure_attention":
+        A = d["p.attention.encoder_att.weight"].shape[0]
+        m = PureAttention(A, M, D, V, encoder_dim=E, dropout=0.0)
+    else:
+        S, F4 = d["p.decode_step.weight_ib"].shape
+        if kind == "attention_scn":
+            A = d["p.attention.encoder_att.weight"].shape[0]
+            m = AttentionSCN(A, M, D, F4 // 4, S, V, encoder_dim=E, dropout=0.0)
+        else:
+            m = PureSCN(M, D, F4 // 4, S, V, encoder_dim=E, dropout=0.0)
+    m.load_state_dict(params_from(d))
+    return m.to(dev).train()
+
+
+@pytest.mark.parametrize("name,kind", [
+    ("attention_scn_distinct", "attention_scn"), ("attention_scn_tied", "attention_scn"),
+    ("attention_scn_full", "attention_scn"), ("attention_scn_odd", "attention_scn"),
+    ("pure_scn_distinct", "pure_scn"), ("pure_attention_distinct", "pure_attention")])
+def test_decoder_golden(dev, name, kind):
+    from oracle import scnattn_ref as R
+    d = load_golden(name)
+    m = _build_decoder(kind, d, dev)
+    enc = t(d["enc"]).to(dev).requires_grad_(True)
+    tags, caps, caplens = t(d["tags"]).to(dev), t(d["caps"]).to(dev), t(d["caplens"]).to(dev)
+    si = t(d["sort_ind"]).to(dev)
+    if kind == "pure_attention":
+        preds, caps_s, dl, alphas, sort_ind = m(enc, caps, caplens, sort_ind=si)
+    elif kind == "pure_scn":
+        preds, caps_s, dl, sort_ind = m(enc, tags, caps, caplens, sort_ind=si)
+        alphas = None
+    else:
+        preds, caps_s, dl, alphas, sort_ind = m(enc, tags, caps, caplens, sort_ind=si)
+    _ok(preds, d["preds"], TOL_OUT, "preds")
+    assert np.array_equal(caps_s.cpu().numpy(), d["caps_sorted"])
+    assert list(dl) == list(d["decode_lengths"])
+    if alphas is not None:
+        _ok(alphas, d["alphas"], TOL_OUT, "alphas")
+    for b, l in enumerate(dl):  # B8: cells past the decode length are exactly zero
+        if l < preds.size(1):
+            assert preds[b, l:].abs().max().item() == 0.0
+            if alphas is not None:
+                assert alphas[b, l:].abs().max().item() == 0.0
+    loss, sc, tg = R.caption_loss(preds, caps_s, dl, alphas, 1.0)
+    _ok(loss, d["loss"], TOL_OUT, "loss")
+    loss.backward()
+    for k, p in m.named_parameters():
+        key = "g_raw." + k
+        if key in d:
+            _ok(p.grad, d[key], TOL_GRAD, k)
+    _ok(enc.grad, d["denc"], TOL_GRAD, "denc")
+
+
+def test_decoder_sort_is_done_on_device(dev):
+    """Without an injected permutation the module's own stable sort must reproduce the reference's
+    permutation for distinct lengths."""
+    d = load_golden("attention_scn_distinct")
+    m = _build_decoder("attention_scn", d, dev)
+    out = m(t(d["enc"]).to(dev), t(d["tags"]).to(dev), t(d["caps"]).to(dev), t(d["caplens"]).to(dev))
+    assert np.array_equal(out[4].cpu().numpy(), d["sort_ind"])
+    _ok(out[0], d["preds"], TOL_OUT)
+
+
+@pytest.mark.parametrize("kind,ragged", [("attention_scn", False), ("attention_scn", True), ("pure_scn", True)])
+def test_decoder_full_size_vs_oracle(dev, kind, ragged):
+    """BASELINE dims (B=32, P=196, E=2048, A=D=F=M=512, S=1000) at a reduced vocabulary / length so that
+    the CPU oracle finishes in seconds; forward, loss and every gradient."""
+    from oracle import scnattn_ref as R
+    from models.decoders.attention_scn import AttentionSCN
+    from models.decoders.pure_scn import PureSCN
+    torch.manual_seed(7)
+    B, V, L = 32, 1000, 14
+    if kind == "attention_scn":
+        m = AttentionSCN(512, 512, 512, 512, 1000, V, dropout=0.5)
+    else:
+        m = PureSCN(512, 512, 512, 1000, V, dropout=0.5)
+    g = torch.Generator().manual_seed(11)
+    enc = torch.rand(B, 14, 14, 2048, generator=g)
+    tags = torch.rand(B, 1000, generator=g)
+    lens = torch.randint(5, L + 1, (B,), generator=g) if ragged else torch.full((B,), L)
+    caps = torch.zeros(B, L, dtype=torch.long)
+    for b in range(B):
+        n = int(lens[b])
+        caps[b, 0] = V - 2
+        caps[b, 1:n - 1] = torch.randint(1, V - 3, (n - 2,), generator=g)
+        caps[b, n - 1] = V - 1
+    caplens = lens.unsqueeze(1)
+    T = int(lens.max()) - 1
+    mask = (torch.rand(B, T, 512, generator=g) > 0.5).float() * 2.0
+    si = torch.sort(lens, descending=True, stable=True)[1]
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    e1 = enc.clone().requires_grad_(True)
+    if kind == "attention_scn":
+        pr, cs, dl, al, _ = R.attention_scn_forward(P, e1, tags, caps, caplens, drop_mask=mask, sort_ind=si, hoist=True)
+    else:
+        pr, cs, dl, _ = R.pure_scn_forward(P, e1, tags, caps, caplens, drop_mask=mask, sort_ind=si)
+        al = None
+    loss_r, _, _ = R.caption_loss(pr, cs, dl, al, 1.0)
+    loss_r.backward()
+    m = m.to(dev).train()
+    m.drop_mask_override = mask.to(dev)
+    e2 = enc.to(dev).requires_grad_(True)
+    out = m(e2, tags.to(dev), caps.to(dev), caplens.to(dev), sort_ind=si.to(dev))
+    preds, alphas = out[0], (out[3] if kind == "attention_scn" else None)
+    _ok(preds, pr, TOL_OUT, "preds")
+    if alphas is not None:
+        _ok(alphas, al, TOL_OUT, "alphas")
+    loss, _, _ = R.caption_loss(preds, out[1], out[2], alphas, 1.0)
+    _ok(loss, loss_r, TOL_OUT, "loss")
+    loss.backward()
+    worst = 0.0
+    for k, p in m.named_parameters():
+        worst = max(worst, _ok(p.grad, P[k].grad, TOL_GRAD, k))
+    _ok(e2.grad, e1.grad, TOL_GRAD, "denc")
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cl", [False, True])
+def test_pool_permute(dev, cl):
+    from scnattn import functional as SF
+    from oracle import scnattn_ref as R
+    torch.manual_seed(0)
+    x = torch.randn(3, 70, 8, 8)
+    xr = x.clone().requires_grad_(True)
+    yr = R.pool_permute(xr, 14)
+    w = torch.randn_like(yr)
+    (yr * w).sum().backward()
+    xd = x.to(dev)
+    if cl:
+        xd = xd.contiguous(memory_format=torch.channels_last)
+    xd.requires_grad_(True)
+    y = SF.pool_permute(xd, 14)
+    _ok(y, yr, 1e-6)
+    (y * w.to(dev)).sum().backward()
+    _ok(xd.grad, xr.grad, 1e-6)
+
+
+def test_clamp_adam_matches_torch(dev):
+    from scnattn import functional as SF
+    torch.manual_seed(1)
+    n = 10007
+    p0 = torch.randn(n)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=4e-4)
+    p, m, v = p0.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    for step in range(1, 4):
+        g = torch.randn(n) * 4.0
+        pr.grad = g.clone().clamp_(-5.0, 5.0)   # utils/optimizer.py clip_gradient
+        opt.step()
+        SF.clamp_adam_(p, g.to(dev), m, v, 4e-4, step, 5.0)
+        _ok(p, pr.detach(), 1e-6, "adam step %d" % step)
