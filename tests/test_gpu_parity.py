@@ -32,6 +32,28 @@ def _ok(a, b, tol, what=""):
     return e
 
 
+def _check_grads(named, ref_of, tol, floors=None, report=None):
+    """Compare every gradient; softmax shift-invariance makes d/d(full_att.bias) exactly 0 in exact
+    arithmetic, so that one is checked absolutely (both sides are rounding noise)."""
+    bad = []
+    for k, p in named:
+        r = ref_of(k)
+        if r is None:
+            continue
+        if k.endswith("full_att.bias"):
+            err = (p.grad.detach().double().cpu() - torch.as_tensor(r).double()).abs().max().item()
+            lim = 1e-4   # exact value is 0; both sides are accumulated rounding noise
+        else:
+            err, lim = rel_err(p.grad, r), tol
+            if floors is not None:
+                lim = max(lim, floors.get(k, 0.0))
+        if report is not None:
+            report.append("%-40s err %.3e lim %.1e" % (k, err, lim))
+        if err > lim:
+            bad.append("%s err %.3e > %.1e" % (k, err, lim))
+    assert not bad, "; ".join(bad)
+
+
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (37, 53, 29), (300, 130, 257), (1, 700, 96), (196, 512, 2048)])
@@ -43,14 +65,15 @@ def test_sgemm(dev, ta, tb, M, N, K):
     bias = torch.randn(N, generator=g)
     c0 = torch.randn(M, N, generator=g)
     ref = (a.double().t() if ta else a.double()) @ (b.double().t() if tb else b.double())
+    tol = 2e-6 * max(1.0, (K / 256.0) ** 0.5)   # fp32 accumulation error grows ~ sqrt(K)
     out = SF.gemm(a.to(dev), b.to(dev), ta=bool(ta), tb=bool(tb))
-    _ok(out, ref, 2e-6, "gemm")
+    _ok(out, ref, tol, "gemm")
     out2 = c0.to(dev).clone()
     SF.gemm(a.to(dev), b.to(dev), ta=bool(ta), tb=bool(tb), bias=bias.to(dev), out=out2, beta=0.5, alpha=2.0)
-    _ok(out2, 2.0 * ref + 0.5 * c0.double() + bias.double(), 2e-6, "gemm epilogue")
+    _ok(out2, 2.0 * ref + 0.5 * c0.double() + bias.double(), tol, "gemm epilogue")
     mask = (torch.arange(M) % 3 != 0).float()
     out3 = SF.gemm(a.to(dev), b.to(dev), ta=bool(ta), tb=bool(tb), bias=bias.to(dev), rowmask=mask.to(dev))
-    _ok(out3, (ref + bias.double()) * mask.double()[:, None], 2e-6, "gemm rowmask")
+    _ok(out3, (ref + bias.double()) * mask.double()[:, None], tol, "gemm rowmask")
     assert out3[0].abs().max().item() == 0.0
 
 
@@ -99,8 +122,26 @@ def test_attention_module_golden(dev):
     _ok(awe, d["awe"], TOL_OUT, "awe"); _ok(alpha, d["alpha"], TOL_OUT, "alpha")
     ((awe * t(d["w_awe"]).to(dev)).sum() + (alpha * t(d["w_alpha"]).to(dev)).sum()).backward()
     _ok(enc.grad, d["denc"], TOL_GRAD, "denc"); _ok(h.grad, d["dh"], TOL_GRAD, "dh")
-    for k, p in m.named_parameters():
-        _ok(p.grad, d["g." + k], TOL_GRAD, k)
+    _check_grads(m.named_parameters(), lambda k: d["g." + k], TOL_GRAD)
+
+
+def _report(lines, title):
+    """Append a per-tensor error table to gpurun_out/parity_report.txt (kept with the run's output)."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "parity_report.txt"), "a") as f:
+        f.write("== %s\n" % title)
+        for ln in lines:
+            f.write(ln + "\n")
+
+
+def _floors(g32, g64, mult=3.0):
+    """Conditioning floor per tensor: how far the reference's own fp32 CPU arithmetic is from fp64.
+    ReLU'(x) is discontinuous at 0: a pre-activation within rounding of 0 flips its mask bit between
+    two equally valid fp32 evaluations and moves a whole gradient row by O(1/sqrt(#terms)).  A HIP
+    gradient is accepted when it is within max(TOL_GRAD, 3 x that floor) of the fp64 oracle."""
+    return {k: mult * rel_err(g32[k], g64[k]) for k in g32}
 
 
 def test_attention_module_full_size(dev):
@@ -110,20 +151,31 @@ def test_attention_module_full_size(dev):
     B, Pn, E, D, A = 8, 196, 2048, 512, 512
     m = Attention(E, D, A)
     enc, h = torch.rand(B, Pn, E), torch.randn(B, D) * 0.5
-    P = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
-    e1, h1 = enc.clone().requires_grad_(True), h.clone().requires_grad_(True)
-    awe_r, al_r = R.attention_forward(P, "", e1, h1)
     wa, wl = torch.randn(B, E), torch.randn(B, Pn)
-    ((awe_r * wa).sum() + (al_r * wl).sum()).backward()
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        P = {k: v.detach().clone().to(dt).requires_grad_(True) for k, v in m.state_dict().items()}
+        e1, h1 = enc.clone().to(dt).requires_grad_(True), h.clone().to(dt).requires_grad_(True)
+        awe_r, al_r = R.attention_forward(P, "", e1, h1)
+        ((awe_r * wa.to(dt)).sum() + (al_r * wl.to(dt)).sum()).backward()
+        g = {k: v.grad for k, v in P.items()}
+        g["__enc"], g["__h"] = e1.grad, h1.grad
+        res[dt] = (awe_r.detach(), al_r.detach(), g)
+    floors = _floors(res[torch.float32][2], res[torch.float64][2])
+    awe64, al64, g64 = res[torch.float64]
     m = m.to(dev)
     e2, h2 = enc.to(dev).requires_grad_(True), h.to(dev).requires_grad_(True)
     awe, al = m(e2, h2)
-    _ok(awe, awe_r, TOL_OUT, "awe"); _ok(al, al_r, TOL_OUT, "alpha")
+    _ok(awe, awe64, TOL_OUT, "awe"); _ok(al, al64, TOL_OUT, "alpha")
     assert abs(al.sum(1).max().item() - 1.0) < 1e-5
     ((awe * wa.to(dev)).sum() + (al * wl.to(dev)).sum()).backward()
-    _ok(e2.grad, e1.grad, TOL_GRAD, "denc"); _ok(h2.grad, h1.grad, TOL_GRAD, "dh")
-    for k, p in m.named_parameters():
-        _ok(p.grad, P[k].grad, TOL_GRAD, k)
+    rep = []
+    _ok(e2.grad, g64["__enc"], max(TOL_GRAD, floors["__enc"]), "denc")
+    _ok(h2.grad, g64["__h"], max(TOL_GRAD, floors["__h"]), "dh")
+    try:
+        _check_grads(m.named_parameters(), lambda k: g64[k], TOL_GRAD, floors, rep)
+    finally:
+        _report(rep, "attention full size")
 
 
 def test_scn_cell_module_golden(dev):
@@ -210,10 +262,7 @@ def test_decoder_golden(dev, name, kind):
     loss, sc, tg = R.caption_loss(preds, caps_s, dl, alphas, 1.0)
     _ok(loss, d["loss"], TOL_OUT, "loss")
     loss.backward()
-    for k, p in m.named_parameters():
-        key = "g_raw." + k
-        if key in d:
-            _ok(p.grad, d[key], TOL_GRAD, k)
+    _check_grads(m.named_parameters(), lambda k: d.get("g_raw." + k), TOL_GRAD)
     _ok(enc.grad, d["denc"], TOL_GRAD, "denc")
 
 
@@ -230,7 +279,7 @@ def test_decoder_sort_is_done_on_device(dev):
 @pytest.mark.parametrize("kind,ragged", [("attention_scn", False), ("attention_scn", True), ("pure_scn", True)])
 def test_decoder_full_size_vs_oracle(dev, kind, ragged):
     """BASELINE dims (B=32, P=196, E=2048, A=D=F=M=512, S=1000) at a reduced vocabulary / length so that
-    the CPU oracle finishes in seconds; forward, loss and every gradient."""
+    the CPU oracle finishes in seconds; forward, loss and every gradient, anchored on the fp64 oracle."""
     from oracle import scnattn_ref as R
     from models.decoders.attention_scn import AttentionSCN
     from models.decoders.pure_scn import PureSCN
@@ -254,30 +303,43 @@ def test_decoder_full_size_vs_oracle(dev, kind, ragged):
     T = int(lens.max()) - 1
     mask = (torch.rand(B, T, 512, generator=g) > 0.5).float() * 2.0
     si = torch.sort(lens, descending=True, stable=True)[1]
-    P = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
-    e1 = enc.clone().requires_grad_(True)
-    if kind == "attention_scn":
-        pr, cs, dl, al, _ = R.attention_scn_forward(P, e1, tags, caps, caplens, drop_mask=mask, sort_ind=si, hoist=True)
-    else:
-        pr, cs, dl, _ = R.pure_scn_forward(P, e1, tags, caps, caplens, drop_mask=mask, sort_ind=si)
-        al = None
-    loss_r, _, _ = R.caption_loss(pr, cs, dl, al, 1.0)
-    loss_r.backward()
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        P = {k: v.detach().clone().to(dt).requires_grad_(True) for k, v in m.state_dict().items()}
+        e1 = enc.clone().to(dt).requires_grad_(True)
+        if kind == "attention_scn":
+            pr, cs, dl, al, _ = R.attention_scn_forward(P, e1, tags.to(dt), caps, caplens, drop_mask=mask.to(dt),
+                                                        sort_ind=si, hoist=True)
+        else:
+            pr, cs, dl, _ = R.pure_scn_forward(P, e1, tags.to(dt), caps, caplens, drop_mask=mask.to(dt), sort_ind=si)
+            al = None
+        loss_r, _, _ = R.caption_loss(pr, cs, dl, al, 1.0)
+        loss_r.backward()
+        gr = {k: v.grad for k, v in P.items()}
+        gr["__enc"] = e1.grad
+        res[dt] = (pr.detach(), None if al is None else al.detach(), loss_r.detach(), gr)
+    floors = _floors(res[torch.float32][3], res[torch.float64][3])
+    pr64, al64, loss64, g64 = res[torch.float64]
     m = m.to(dev).train()
     m.drop_mask_override = mask.to(dev)
     e2 = enc.to(dev).requires_grad_(True)
     out = m(e2, tags.to(dev), caps.to(dev), caplens.to(dev), sort_ind=si.to(dev))
     preds, alphas = out[0], (out[3] if kind == "attention_scn" else None)
-    _ok(preds, pr, TOL_OUT, "preds")
+    rep = ["preds  err %.3e (cpu fp32 vs fp64: %.3e)" % (rel_err(preds, pr64), rel_err(res[torch.float32][0], pr64))]
+    _ok(preds, pr64, TOL_OUT, "preds")
     if alphas is not None:
-        _ok(alphas, al, TOL_OUT, "alphas")
+        rep.append("alphas err %.3e" % rel_err(alphas, al64))
+        _ok(alphas, al64, TOL_OUT, "alphas")
     loss, _, _ = R.caption_loss(preds, out[1], out[2], alphas, 1.0)
-    _ok(loss, loss_r, TOL_OUT, "loss")
+    _ok(loss, loss64, TOL_OUT, "loss")
     loss.backward()
-    worst = 0.0
-    for k, p in m.named_parameters():
-        worst = max(worst, _ok(p.grad, P[k].grad, TOL_GRAD, k))
-    _ok(e2.grad, e1.grad, TOL_GRAD, "denc")
+    try:
+        _check_grads(m.named_parameters(), lambda k: g64[k], TOL_GRAD, floors, rep)
+        rep.append("%-40s err %.3e lim %.1e" % ("d/d encoder_out", rel_err(e2.grad, g64["__enc"]),
+                                                 max(TOL_GRAD, floors["__enc"])))
+        _ok(e2.grad, g64["__enc"], max(TOL_GRAD, floors["__enc"]), "denc")
+    finally:
+        _report(rep, "decoder full size %s ragged=%s" % (kind, ragged))
 
 
 # ------------------------------------------------------------------------------------------------
