@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""bench.py -- images/sec of one train step of the SCN+Attention captioner on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N=1 default; N>1 under torch.distributed.run)
+
+A "step" = trains/attention_scn.py:212-252 on one synthetic batch per rank (32 images 256x256, 52-token
+captions, 1000 tags, V=10000, fp32): ResNet-152 encoder fwd (fine-tuning layer2-4) -> AttentionSCN
+decoder fwd -> loss -> zero_grad -> backward (+ RCCL gradient all-reduce when N>1) -> clamp +-5 -> Adam.
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+Extra objects in the line (task contract):
+  roofline     -- the per-timestep decode kernel group (the "fused SCN-cell + attention step" of
+                  north_star; 6 launches per step in this round): algorithmic bytes per step
+                  (enc + att1 + recurrent weights) / average step duration measured with
+                  HIP events recorded by the library on the launch stream, against HBM peak 8 TB/s.
+  cpu_baseline -- the CPU oracle (op-for-op restatement of the reference, oracle/scnattn_ref.py) timed
+                  on the host cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "indonesian-image-captioning_amd"), ROOT):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def step_bytes(cfg, B, P=196, E=2048):
+    """Algorithmic fp32 bytes one forward decode step must move at batch B:
+    enc (B,P,E) + att1 (B,P,A) + recurrent weights (decoder_att, f_beta, weight_ia[M:], weight_ic/ha/hc)."""
+    A, D, F = cfg["attention_dim"], cfg["decoder_dim"], cfg["factored_dim"]
+    weights = D * A + D * E + E * 4 * F + 3 * D * 4 * F
+    return 4 * (B * P * E + B * P * A + weights)
+
+
+def cpu_baseline(kind, cfg, fine_tune, budget_s=30.0):
+    """Time the CPU oracle on a bounded sample: ONE full train step at a reduced batch (B=4), full
+    sequence length / vocabulary / model size; images/sec = B / time."""
+    from oracle import scnattn_ref as R
+    from scnattn.resnet import resnet152_trunk
+    from trains.harness import build_decoder, synthetic_batch
+    # the GPU box exposes every host core but grants a 16-core share per GPU: more threads than that
+    # only oversubscribes
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    ncores = max(1, min(ncores, 16))
+    torch.set_num_threads(ncores)
+    torch.manual_seed(0)
+    Bc = 4
+    dec = build_decoder(kind, dict(cfg, dropout=0.0))
+    P = {k: v.detach().clone() for k, v in dec.state_dict().items()}
+    trunk = resnet152_trunk().train()
+    for i, child in enumerate(trunk.children()):
+        for p in child.parameters():
+            p.requires_grad = bool(fine_tune and i >= 5)
+    enc_opt = torch.optim.Adam([p for p in trunk.parameters() if p.requires_grad], lr=cfg["encoder_lr"]) \
+        if fine_tune else None
+    imgs, tags, caps, caplens = synthetic_batch(Bc, cfg["vocab_size"], cfg["max_len"], cfg["image_size"],
+                                                cfg["semantic_dim"], "cpu", 99)
+    t0 = time.perf_counter()
+    feat = trunk(imgs)
+    enc = R.pool_permute(feat, 14)
+    enc_leaf = enc.detach().requires_grad_(fine_tune)
+    loss, _, denc = R.decoder_train_step(kind, P, enc_leaf, tags, caps, caplens, {}, 1, lr=cfg["decoder_lr"],
+                                         grad_clip=cfg["grad_clip"], alpha_c=cfg["alpha_c"],
+                                         enc_requires_grad=fine_tune)
+    if fine_tune:
+        enc_opt.zero_grad()
+        enc.backward(denc)
+        for p in trunk.parameters():
+            if p.grad is not None:
+                p.grad.clamp_(-cfg["grad_clip"], cfg["grad_clip"])
+        enc_opt.step()
+    dt = time.perf_counter() - t0
+    return {"value": round(Bc / dt, 4), "unit": "images/sec", "cores": ncores, "kind": "port",
+            "sample": "1 full train step (encoder%s + un-hoisted %s decoder, T=%d, V=%d) at batch %d, %.1f s, "
+                      "torch CPU fp32 with %d threads" % (" fine-tune" if fine_tune else " frozen", kind,
+                                                          cfg["max_len"] + 1, cfg["vocab_size"], Bc, dt, ncores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="attention_scn", choices=["attention_scn", "pure_scn", "pure_attention"])
+    ap.add_argument("--no-finetune", action="store_true", help="freeze the encoder (reference default)")
+    ap.add_argument("--decoder-only", action="store_true", help="feed a synthetic encoder_out (diagnostics)")
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--max-len", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ksplit", type=int, default=0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    from scnattn import _lib
+    from scnattn import functional as SF
+    from trains.harness import TrainStep, synthetic_batch, DEFAULTS
+    if args.ksplit:
+        SF.set_option("ksplit", args.ksplit)
+    fine_tune = not args.no_finetune
+    ts = TrainStep(kind=args.workload, fine_tune_encoder=fine_tune, device=dev, encoder=not args.decoder_only,
+                   batch_size=args.batch, max_len=args.max_len)
+    cfg = ts.cfg
+    imgs, tags, caps, caplens = synthetic_batch(args.batch, cfg["vocab_size"], cfg["max_len"], cfg["image_size"],
+                                                cfg["semantic_dim"], dev, 1234 + rank)
+    enc_in = None
+    if args.decoder_only:
+        enc_in = torch.rand(args.batch, 14, 14, 2048, device=dev)
+
+    def run(n):
+        for _ in range(n):
+            ts.step(imgs, tags, caps, caplens, enc_in)
+
+    run(args.warmup)
+    SF.set_option("profile", 1)
+    prof = (ctypes.c_double * 4)()
+    torch.cuda.synchronize()
+    _lib.call("scnattn_profile_collect", prof)   # drop warm-up events
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    _lib.call("scnattn_profile_collect", prof)
+    SF.set_option("profile", 0)
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        ms_step = 1e3 * elapsed / args.steps
+        value = world * args.batch * args.steps / elapsed
+        T = cfg["max_len"] + 1
+        out = {
+            "metric": "images/sec (train step, SCN+Attention, bs32/GPU)" if args.workload == "attention_scn"
+            else "images/sec (train step, %s, bs%d/GPU)" % (args.workload, args.batch),
+            "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s decoder (emb/att/factor/dec=512, 1000 tags, V=%d, T=%d)%s, bs=%d/GPU, "
+                                   "256x256 images, fp32" % (args.workload, cfg["vocab_size"], T,
+                                                             " decoder only" if args.decoder_only else
+                                                             (" + ResNet-152 fine-tune" if fine_tune
+                                                              else " + frozen ResNet-152"), args.batch),
+                       "global_batch": world * args.batch, "parallelism": "dp%d" % world},
+        }
+        if args.workload == "attention_scn" and prof[1] > 0:
+            step_us = 1e3 * prof[0] / prof[1]
+            ab = step_bytes(cfg, args.batch)
+            ach = ab / (step_us * 1e-6) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                               "kernel": "decode step fwd = skinny_kernel x3 + attn_scores + attn_context + "
+                                         "scn_mix_fwd + lstm_fwd (the fused SCN-cell+attention step)",
+                               "algorithmic_bytes_per_step": ab, "avg_step_us": round(step_us, 2),
+                               "bwd_avg_step_us": round(1e3 * prof[2] / prof[3], 2) if prof[3] > 0 else None}
+        if world == 1 and not args.no_cpu_baseline and not args.decoder_only:
+            print("[bench] GPU part done: %.1f images/sec; timing the CPU oracle sample ..." % value,
+                  file=sys.stderr, flush=True)
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.workload, cfg, fine_tune)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                out["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

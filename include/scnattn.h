@@ -27,8 +27,12 @@ extern "C" {
 
 int scnattn_version(void);
 const char* scnattn_last_error(void);
-/* Tuning knobs (e.g. "ksplit_scale"); returns -1 for an unknown name. */
+/* Options: "ksplit" (force the split-K factor of the skinny GEMMs; 0 = auto), "profile" (1: bracket
+ * the recurrence loops with HIP events on the caller's stream).  Returns -1 for an unknown name. */
 int scnattn_set_option(const char* name, int value);
+/* Sum of the event-timed recurrence loops since the last call:
+ * out4 = {forward loop ms, forward steps, backward loop ms, backward steps}.  Synchronises on the events. */
+int scnattn_profile_collect(double* out4);
 
 /* ---- dimensions of one decoder (models/decoders/attention_scn.py:28-56, pure_scn.py:26-48) ------ */
 typedef struct {

@@ -20,6 +20,8 @@ void set_error(const char* fmt, ...) {
 const char* last_error() { return g_err; }
 
 extern int g_ksplit_scale;
+extern int g_profile;
+int profile_collect(double* out);
 int seq_workspace(const scnattn_dims* d, size_t* saved_bytes, size_t* scratch_bytes);
 int seq_fwd(hipStream_t st, const scnattn_dims* d, const scnattn_params* w, const float* enc, const float* tags,
             const int64_t* caps, const int32_t* dl_dev, const int32_t* bt, const float* drop_mask, float* saved,
@@ -44,8 +46,17 @@ int scnattn_set_option(const char* name, int value) {
         g_ksplit_scale = value;
         return 0;
     }
+    if (name && std::strcmp(name, "profile") == 0) {
+        g_profile = value;
+        return 0;
+    }
     set_error("scnattn_set_option: unknown option '%s'", name ? name : "(null)");
     return -1;
+}
+
+int scnattn_profile_collect(double* out4) {
+    if (!out4) { set_error("scnattn_profile_collect: NULL"); return -1; }
+    return profile_collect(out4);
 }
 
 int scnattn_seq_workspace(const scnattn_dims* d, size_t* saved_bytes, size_t* scratch_bytes) {

@@ -56,10 +56,40 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // Sum `nslab` partial slabs (split-K outputs of skinny_gemm) at element `idx`, fixed order.
-__device__ __forceinline__ float slab_sum(const float* __restrict__ p, long idx, int nslab, long stride) {
-    float s = p[idx];
-    for (int i = 1; i < nslab; ++i) s += p[idx + (long)i * stride];
+// All loads are issued before the first add (a run-time-bounded loop would serialise one memory
+// latency per slab): loads beyond n re-read the last slab (a cache hit) and are discarded.
+template <int MAXN>
+__device__ __forceinline__ float slab_sum_u(const float* __restrict__ p, long idx, int n, long stride) {
+    float v[MAXN];
+#pragma unroll
+    for (int i = 0; i < MAXN; ++i) v[i] = p[idx + (long)min(i, n - 1) * stride];
+    float s = v[0];
+#pragma unroll
+    for (int i = 1; i < MAXN; ++i) s += (i < n) ? v[i] : 0.f;
     return s;
+}
+__device__ __forceinline__ float slab_sum(const float* __restrict__ p, long idx, int nslab, long stride) {
+    if (nslab <= 1) return p[idx];
+    if (nslab <= 2) return slab_sum_u<2>(p, idx, nslab, stride);
+    if (nslab <= 4) return slab_sum_u<4>(p, idx, nslab, stride);
+    if (nslab <= 8) return slab_sum_u<8>(p, idx, nslab, stride);
+    return slab_sum_u<16>(p, idx, nslab, stride);
+}
+
+// ---- buffer loads with hardware range checking (out-of-range lanes read 0, no branches) -------------
+// hipcc turns "load from a clamped address, then select" back into a branch around the load and waits
+// vmcnt(0) after every one of them, which serialises a whole memory latency per load.  A raw buffer
+// load cannot be predicated that way: lanes that must not contribute get the offset OOB_OFF.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB_OFF = 0x80000000u;   // > any num_records we build (checked on the host)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
 
 // row (0..31) of accumulator register r of lane l in a 32x32 f32 MFMA C/D tile; column is l & 31.

@@ -36,19 +36,28 @@ __global__ __launch_bounds__(256) void copy2d_kernel(int R, int C, const float* 
     out[(long)r * ldo + c] = in[(long)r * ldi + c];
 }
 
-// out[n] = beta*out[n] + sum_r X[r][n]; one workgroup per 64 columns, 4 row lanes, fixed order.
+// out[n] = beta*out[n] + sum_r X[r][n]; one workgroup per 16 columns x 16 row lanes, 4 independent
+// loads in flight per thread, fixed summation order (deterministic).
 __global__ __launch_bounds__(256) void colsum_kernel(int R, int N, const float* __restrict__ X, long ld,
                                                      float* __restrict__ out, float beta) {
-    __shared__ float part[4][64];
-    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int n = blockIdx.x * 64 + c;
-    float s = 0.f;
-    if (n < N)
-        for (int r = rl; r < R; r += 4) s += X[(long)r * ld + n];
-    part[rl][c] = s;
+    __shared__ float part[16][17];
+    const int c = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int n = blockIdx.x * 16 + c;
+    const int nc = min(n, N - 1);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = rl;
+    for (; r + 48 < R; r += 64) {
+        const float a0 = X[(long)r * ld + nc], a1 = X[(long)(r + 16) * ld + nc];
+        const float a2 = X[(long)(r + 32) * ld + nc], a3 = X[(long)(r + 48) * ld + nc];
+        s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+    }
+    for (; r < R; r += 16) s0 += X[(long)r * ld + nc];
+    part[rl][c] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (rl == 0 && n < N) {
-        const float v = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
+        float v = part[0][c];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) v += part[i][c];
         out[n] = (beta != 0.f ? beta * out[n] : 0.f) + v;
     }
 }
@@ -241,7 +250,7 @@ int copy2d(hipStream_t st, int R, int C, const float* in, long ldi, float* out, 
 int colsum(hipStream_t st, int R, int N, const float* X, long ld, float* out, float beta) {
     if (N <= 0) return 0;
     SCN_ARG(X && out && R >= 0, "colsum: bad argument");
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64)), dim3(256), 0, st, R, N, X, ld, out, beta);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 16)), dim3(256), 0, st, R, N, X, ld, out, beta);
     SCN_LAUNCH_CHECK();
     return 0;
 }

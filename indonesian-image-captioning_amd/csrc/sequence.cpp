@@ -11,6 +11,8 @@
 //     the stacked (t,b) rows kept in `scratch`, and d att1 / d enc are formed once after the loop.
 #include <hip/hip_runtime.h>
 #include <cstring>
+#include <mutex>
+#include <vector>
 #include "../../include/scnattn.h"
 #include "common.h"
 #include "kernels.h"
@@ -18,6 +20,48 @@
 namespace scn {
 
 int g_ksplit_scale = 0;  // 0 = auto; >0 forces ksplit for every skinny launch (tuning/testing)
+int g_profile = 0;       // 1: bracket the recurrence loops with HIP events (scnattn_profile_collect)
+
+// ---- optional in-stream timing of the recurrence loops (bench.py's roofline figure) ------------------
+struct LoopEvent { hipEvent_t a, b; int kind, steps; };
+static std::mutex g_prof_mu;
+static std::vector<LoopEvent> g_prof;
+
+static hipEvent_t prof_begin(hipStream_t st) {
+    if (!g_profile) return nullptr;
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    (void)hipEventRecord(e, st);
+    return e;
+}
+static void prof_end(hipStream_t st, hipEvent_t a, int kind, int steps) {
+    if (!a) return;
+    hipEvent_t b = nullptr;
+    if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return; }
+    (void)hipEventRecord(b, st);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back(LoopEvent{a, b, kind, steps});
+}
+
+// out[0..3] = {fwd loop ms, fwd steps, bwd loop ms, bwd steps} summed since the last collect
+int profile_collect(double* out) {
+    std::vector<LoopEvent> ev;
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        ev.swap(g_prof);
+    }
+    out[0] = out[1] = out[2] = out[3] = 0.0;
+    for (auto& e : ev) {
+        float ms = 0.f;
+        SCN_HIP(hipEventSynchronize(e.b));
+        SCN_HIP(hipEventElapsedTime(&ms, e.a, e.b));
+        out[e.kind * 2] += ms;
+        out[e.kind * 2 + 1] += e.steps;
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    return 0;
+}
 
 namespace {
 
@@ -209,6 +253,7 @@ int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
 
     // ---- the recurrence --------------------------------------------------------------------------
     const long BD = (long)B * D;
+    hipEvent_t ev0 = prof_begin(st);
     for (int t = 0; t < T; ++t) {
         const int bt_ = bt[t];
         const float* h = s.Hs + t * BD;
@@ -237,6 +282,8 @@ int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
                          c, s.gates_all + (long)t * B * 4 * D, s.Cs + (t + 1) * BD, s.Hs + (t + 1) * BD,
                          s.tanhc_all + t * BD));
     }
+
+    prof_end(st, ev0, 0, T);
 
     // ---- dropout + fc over all (b,t) rows at once ------------------------------------------------
     SCN_TRY(hidden_to_bm(st, B, T, D, dl_dev, s.Hs + BD, drop_mask, s.Hd_bm, s.rowmask));
@@ -291,6 +338,7 @@ int seq_bwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
 
     // ---- reverse recurrence ----------------------------------------------------------------------
     int ksH = 0;
+    hipEvent_t ev0 = prof_begin(st);
     for (int t = T - 1; t >= 0; --t) {
         const int bt_ = bt[t];
         const int btn = (t + 1 < T) ? bt[t + 1] : 0;
@@ -321,6 +369,7 @@ int seq_bwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
         ksH = pick(bt_, D, NC, 1);
         SCN_TRY(skinny_gemm(st, bt_, D, NC, 1, dcat, NC, 0, k.WcatT, D, 0, k.sH, D, 0, BD, ksH));
     }
+    prof_end(st, ev0, 1, T);
     SCN_TRY(reduce_slabs(st, B, D, Slabs{k.sH, ksH, BD, D}, k.dh0));  // d loss / d h0; d/d c0 is k.dc
 
     // ---- weight gradients: one GEMM per weight over the stacked (t,b) rows ---------------------------

@@ -30,43 +30,25 @@ struct GemmArgs {
 };
 
 // Load a (128 x 16) operand tile into registers.  CONTIG_K: element (r,k) at base[r*ld + k]
-// (k contiguous) else at base[k*ld + r] (r contiguous).
+// (k contiguous) else at base[k*ld + r] (r contiguous).  Range-checked buffer loads: lanes outside the
+// matrix read 0 with no select and no branch, so nothing forces a wait before the MFMA block.
 template <bool CONTIG_K, bool VEC>
-__device__ __forceinline__ void load_tile(const float* __restrict__ base, long ld, int r0, int k0,
-                                          int R, int K, int tid, float (&reg)[2][4]) {
-    // Loads are unconditional from clamped (always valid) addresses and masked afterwards: a
-    // conditional load makes hipcc branch around it and drain vmcnt per element.
+__device__ __forceinline__ void load_tile(__amdgpu_buffer_rsrc_t rs, long ld, int r0, int k0, int R, int K,
+                                          int tid, float (&reg)[2][4]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        if (CONTIG_K) {
-            const int r = r0 + (tid >> 2) + 64 * i, k = k0 + (tid & 3) * 4;
-            const int rc = min(r, R - 1);
-            if (VEC) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(base + (long)rc * ld + min(k, K - 4));
-                const bool ok = r < R && k < K;
+        const int r = CONTIG_K ? r0 + (tid >> 2) + 64 * i : r0 + (tid & 31) * 4;
+        const int k = CONTIG_K ? k0 + (tid & 3) * 4 : k0 + (tid >> 5) + 8 * i;
+        const long lin = CONTIG_K ? (long)r * ld + k : (long)k * ld + r;
+        if (VEC) {
+            const f32x4 v = buf_load4(rs, (r < R && k < K) ? (unsigned)(lin * 4) : OOB_OFF);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) reg[i][c] = ok ? v[c] : 0.f;
-            } else {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float v = base[(long)rc * ld + min(k + c, K - 1)];
-                    reg[i][c] = (r < R && k + c < K) ? v : 0.f;
-                }
-            }
+            for (int c = 0; c < 4; ++c) reg[i][c] = v[c];
         } else {
-            const int k = k0 + (tid >> 5) + 8 * i, r = r0 + (tid & 31) * 4;
-            const int kc = min(k, K - 1);
-            if (VEC) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(base + (long)kc * ld + min(r, R - 4));
-                const bool ok = k < K && r < R;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) reg[i][c] = ok ? v[c] : 0.f;
-            } else {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float v = base[(long)kc * ld + min(r + c, R - 1)];
-                    reg[i][c] = (k < K && r + c < R) ? v : 0.f;
-                }
+            for (int c = 0; c < 4; ++c) {
+                const bool ok = CONTIG_K ? (r < R && k + c < K) : (k < K && r + c < R);
+                reg[i][c] = buf_load(rs, ok ? (unsigned)((lin + (CONTIG_K ? c : c)) * 4) : OOB_OFF);
             }
         }
     }
@@ -110,8 +92,11 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmArgs g) {
 
     float ra[2][4], rb[2][4];
     const int nk = (g.K + BK - 1) / BK;
-    load_tile<!TA, VEC>(A, g.lda, m0, 0, g.M, g.K, tid, ra);
-    load_tile<TB, VEC>(B, g.ldb, n0, 0, g.N, g.K, tid, rb);
+    // descriptors from wave-uniform values (kernel args + blockIdx.z); sizes checked on the host
+    const __amdgpu_buffer_rsrc_t ars = make_rsrc(A, (unsigned)((TA ? ((long)(g.K - 1) * g.lda + g.M) : ((long)(g.M - 1) * g.lda + g.K)) * 4));
+    const __amdgpu_buffer_rsrc_t brs = make_rsrc(B, (unsigned)((TB ? ((long)(g.N - 1) * g.ldb + g.K) : ((long)(g.K - 1) * g.ldb + g.N)) * 4));
+    load_tile<!TA, VEC>(ars, g.lda, m0, 0, g.M, g.K, tid, ra);
+    load_tile<TB, VEC>(brs, g.ldb, n0, 0, g.N, g.K, tid, rb);
     store_tile<!TA>(As[0], tid, ra);
     store_tile<TB>(Bs[0], tid, rb);
     __syncthreads();
@@ -120,8 +105,8 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmArgs g) {
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
-            load_tile<!TA, VEC>(A, g.lda, m0, (kt + 1) * BK, g.M, g.K, tid, ra);
-            load_tile<TB, VEC>(B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, tid, rb);
+            load_tile<!TA, VEC>(ars, g.lda, m0, (kt + 1) * BK, g.M, g.K, tid, ra);
+            load_tile<TB, VEC>(brs, g.ldb, n0, (kt + 1) * BK, g.N, g.K, tid, rb);
         }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
@@ -136,6 +121,7 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmArgs g) {
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);   // keep the LDS stores of the prefetched tile BEHIND the MFMAs
         if (kt + 1 < nk) {
             store_tile<!TA>(As[cur ^ 1], tid, ra);
             store_tile<TB>(Bs[cur ^ 1], tid, rb);
@@ -143,22 +129,46 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmArgs g) {
         __syncthreads();
     }
 
+    // Epilogue.  The optional reads (beta*C, rowmask) are issued as one batch of range-checked buffer
+    // loads per tile and pinned with an empty asm, otherwise hipcc sinks each load next to its store
+    // behind a vmcnt(0): 16 serialised memory latencies per tile.
+    const bool use_c = g.beta != 0.f, use_m = g.rowmask != nullptr;
+    const __amdgpu_buffer_rsrc_t cr = make_rsrc(C, use_c ? (unsigned)(((long)(g.M - 1) * g.ldc + g.N) * 4) : 0u);
+    const __amdgpu_buffer_rsrc_t mr = make_rsrc(g.rowmask, use_m ? (unsigned)g.M * 4u : 0u);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n = n0 + wn * 64 + j * 32 + l31;
-            if (n >= g.N) continue;
-            const float bv = g.bias ? g.bias[n] : 0.f;
+            const bool nok = n < g.N;
+            float cv[16], mk[16];
+            if (use_c) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 64 + i * 32 + mfma32_row(r, lane);
+                    cv[r] = buf_load(cr, (nok && m < g.M) ? (unsigned)(((long)m * g.ldc + n) * 4) : OOB_OFF);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(cv[r]));
+            }
+            if (use_m) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 64 + i * 32 + mfma32_row(r, lane);
+                    mk[r] = buf_load(mr, m < g.M ? (unsigned)m * 4u : OOB_OFF);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(mk[r]));
+            }
+            float bv = 0.f;
+            if (g.bias && nok) bv = g.bias[n];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + i * 32 + mfma32_row(r, lane);
-                if (m >= g.M) continue;
-                float* cp = C + (long)m * g.ldc + n;
                 float v = g.alpha * acc[i][j][r] + bv;
-                if (g.beta != 0.f) v += g.beta * (*cp);
-                if (g.rowmask && g.rowmask[m] == 0.f) v = 0.f;
-                *cp = v;
+                if (use_c) v += g.beta * cv[r];
+                if (use_m && mk[r] == 0.f) v = 0.f;
+                if (nok && m < g.M) C[(long)m * g.ldc + n] = v;
             }
         }
 }
@@ -171,6 +181,12 @@ int sgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
     if (M <= 0 || N <= 0 || batch <= 0) return 0;
     SCN_ARG(A && B && C, "sgemm: null operand");
     SCN_ARG(K >= 1, "sgemm: K must be >= 1");
+    {
+        const long abytes = (tA ? ((long)(K - 1) * lda + M) : ((long)(M - 1) * lda + K)) * 4;
+        const long bbytes = (tB ? ((long)(N - 1) * ldb + K) : ((long)(K - 1) * ldb + N)) * 4;
+        SCN_ARG(abytes < 0x7fffffffL && bbytes < 0x7fffffffL, "sgemm: operand exceeds the 2 GiB buffer-descriptor range");
+    }
+    SCN_ARG(beta == 0.f || ((long)(M - 1) * ldc + N) * 4 < 0x7fffffffL, "sgemm: C too large for beta != 0");
     GemmArgs g{A, B, C, bias, rowmask, lda, ldb, ldc, sA, sB, sC, M, N, K, alpha, beta};
     // 16-byte loads need: aligned bases/strides and the contiguous extent a multiple of 4
     const int contigA = tA ? M : K, contigB = tB ? K : N;

@@ -9,13 +9,16 @@
 // `groups` = 4 runs the four gate blocks (i,f,o,c) of the factored SCN weights in one grid.
 //
 // Shape of the work: weight-bandwidth bound with a non-trivial MFMA floor (0.59 GFLOP per step at
-// B=32), so the grid is (column tiles x groups) x K-slices ~ 2 workgroups per CU and every SIMD gets
-// a slice of K:
-//   * workgroup = 4 waves = one 32-column tile of one K-slice; the 4 waves split the slice's K range
-//     and reduce their 32x32 accumulators through LDS (fixed order -> deterministic);
+// B=32) and, above all, LATENCY bound (a step is a chain of ~6 dependent launches), so a workgroup
+// puts every global load it will ever need in flight at once:
+//   * workgroup = 4 waves = one 32-column tile of one K-slice (<= 256 k per chunk); the 4 waves split
+//     the slice's K range and reduce their 32x32 accumulators through LDS (fixed order ->
+//     deterministic);
 //   * the weight fragment of v_mfma_f32_32x32x2_f32 (lane l: B[k = l>>5][n = l&31]) is exactly two
-//     full 128-byte lines of a row-major [K][N] matrix, so weights go HBM -> VGPR directly, no LDS;
-//   * the tiny activation tile (32 x K-slice) is staged k-major in LDS once per workgroup;
+//     full 128-byte lines of a row-major [K][N] matrix, so weights go HBM/L2 -> VGPR directly, all
+//     (up to 32) fragments of the wave's K range issued back to back before anything waits;
+//   * the activation fragment is one 16-byte load per lane per 8-k block straight from global memory
+//     (the tile is tiny and L2-resident): no LDS staging and no barrier in front of the MFMA chain;
 //   * split-K partial sums are written as slabs and summed, in slab order, by the consumer kernel's
 //     prologue (a launch boundary is cheaper than an in-kernel grid barrier on this chip).
 #include "common.h"
@@ -25,18 +28,24 @@ namespace scn {
 
 namespace {
 
-constexpr int KC = 256;   // activation rows staged per LDS chunk (k extent)
-constexpr int XLD = 33;   // padded leading dim of the k-major activation tile
-constexpr int UN = 8;     // weight-fragment loads kept in flight per wave per batch
+constexpr int KW = 64;        // k extent per wave per chunk
+constexpr int NBW = KW / 8;   // 8-k blocks per wave per chunk
+constexpr int XLD = 33;       // padded leading dim of the reduction tile
 
 struct SkinnyArgs {
     const float* X; const float* W; float* Y;
     long ldx, xg, ldw, wg, ldy, yg, yslab;
-    int rows, N, K, kslice, groups;
+    int rows, N, K, kslice, groups, xvec;
 };
 
+// Operand mapping of v_mfma_f32_32x32x2_f32: lane l holds A[i = l&31][kk = l>>5] and B[kk][n = l&31].
+// The sum over k is order-free, so within each 8-k block the four MFMAs pair rows (k0+c, k0+4+c),
+// c = 0..3: lane (i, kk) then needs X[i][k0 + 4kk .. k0 + 4kk + 3] -- ONE 16-byte load -- and
+// W[k0 + 4kk + c][n] for c = 0..3.  No LDS staging, no barrier before the MFMA chain.
+// NB = 8-k blocks per wave per chunk (compile-time so that every loop below is branch-free: a run-time
+// bound makes hipcc sink the loads of the optional blocks next to their MFMAs, each behind a vmcnt(0)).
+template <int NB, bool XVEC>
 __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
-    __shared__ float Xs[KC * XLD];
     __shared__ float red[4][32 * XLD];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -44,54 +53,58 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
     const int ct = blockIdx.x % ctiles, grp = blockIdx.x / ctiles;
     const int slice = blockIdx.y, r0 = blockIdx.z * 32;
     const int n0 = ct * 32;
-    const int kbeg = slice * a.kslice;
+    const int kbeg = slice * a.kslice;                 // kslice is a multiple of 32
     const int kend = min(a.K, kbeg + a.kslice);
+    const int per = a.kslice >> 2;                     // k per wave (multiple of 8)
 
-    const float* X = a.X + (long)grp * a.xg;
-    const float* W = a.W + (long)grp * a.wg;
-    const int hh = lane >> 5, l31 = lane & 31;
+    const int kk = lane >> 5, l31 = lane & 31;
     const int n = n0 + l31;
     const bool nok = n < a.N;
-    const int nc = nok ? n : a.N - 1;
+    const int row = r0 + l31;
+    const bool rok = row < a.rows;
+    // descriptors are built from wave-uniform values only (kernel args, blockIdx): rows >= kend of W and
+    // rows >= a.rows of X are out of range and read as 0; columns / k beyond the tile get OOB_OFF.
+    const __amdgpu_buffer_rsrc_t wr = make_rsrc(a.W + (long)grp * a.wg, (unsigned)((long)kend * a.ldw * 4));
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.X + (long)grp * a.xg, (unsigned)((long)a.rows * a.ldx * 4));
+    const unsigned wcol = nok ? (unsigned)n * 4u : OOB_OFF;
+    const unsigned xrow = rok ? (unsigned)((long)row * a.ldx * 4) : OOB_OFF;
+    const unsigned ldw4 = (unsigned)a.ldw * 4u;
 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    for (int kc = kbeg; kc < kend; kc += KC) {
-        const int kcn = min(KC, kend - kc);          // k extent of this chunk
-        const int kcn8 = (kcn + 7) & ~7;             // padded so that each wave gets whole k-pairs
-        if (kc != kbeg) __syncthreads();
-        // stage X[r0..r0+31][kc..kc+kcn) k-major; lanes run along k (coalesced), LDS write is 2-way
-        for (int idx = tid; idx < 32 * kcn8; idx += 256) {
-            const int r = idx / kcn8, k = idx - r * kcn8;
-            // unconditional load from a clamped (always valid) address, then select: keeps hipcc from
-            // branching around the load
-            const int rc = min(r0 + r, a.rows - 1), kcl = min(kc + k, a.K - 1);
-            const float v = X[(long)rc * a.ldx + kcl];
-            Xs[k * XLD + r] = (k < kcn && r0 + r < a.rows) ? v : 0.f;
+    for (int c0 = 0; c0 < per; c0 += 8 * NB) {         // per is a multiple of 8*NB (host guarantees it)
+        const int kw0 = kbeg + wave * per + c0;        // first k of this wave's chunk
+        // every load of the chunk is issued before the first MFMA
+        float xf[NB][4], wf[NB][4];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const unsigned k = (unsigned)(kw0 + 8 * j + 4 * kk);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) wf[j][c] = buf_load(wr, nok ? (k + c) * ldw4 + wcol : OOB_OFF);
         }
-        __syncthreads();
-        // this wave's k range inside the chunk: a contiguous quarter, whole k-pairs
-        const int per = kcn8 / 4;                    // multiple of 2
-        const int wk0 = wave * per;
-        const int npair = per / 2;
-        for (int p0 = 0; p0 < npair; p0 += UN) {
-            float bf[UN];
 #pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int k = kc + wk0 + 2 * (p0 + u) + hh;
-                const float v = W[(long)min(k, a.K - 1) * a.ldw + nc];
-                bf[u] = (p0 + u < npair && nok && k < kend) ? v : 0.f;
-            }
+        for (int j = 0; j < NB; ++j) {
+            const int k = kw0 + 8 * j + 4 * kk;
+            if (XVEC) {
+                const f32x4 v = buf_load4(xr, (rok && k < kend) ? xrow + (unsigned)k * 4u : OOB_OFF);
 #pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                if (p0 + u < npair) {
-                    const float af = Xs[(wk0 + 2 * (p0 + u) + hh) * XLD + l31];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf[u], acc, 0, 0, 0);
-                }
+                for (int c = 0; c < 4; ++c) xf[j][c] = v[c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    xf[j][c] = buf_load(xr, (rok && k + c < kend) ? xrow + (unsigned)(k + c) * 4u : OOB_OFF);
             }
         }
+        // keep the scheduler from re-interleaving loads with the MFMA chain (it would hold only ~8 loads
+        // in flight to save registers, i.e. pay a memory latency per 8 MFMAs)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[j][c], wf[j][c], acc, 0, 0, 0);
     }
 
     // cross-wave reduction in wave order 0..3 (deterministic)
@@ -99,7 +112,9 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
     for (int r = 0; r < 16; ++r) red[wave][mfma32_row(r, lane) * XLD + l31] = acc[r];
     __syncthreads();
     float* Y = a.Y + (long)slice * a.yslab + (long)grp * a.yg;
-    for (int idx = tid; idx < 32 * 32; idx += 256) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i;
         const int r = idx >> 5, c = idx & 31;
         if (r0 + r < a.rows && n0 + c < a.N) {
             const float v = ((red[0][r * XLD + c] + red[1][r * XLD + c]) + red[2][r * XLD + c]) + red[3][r * XLD + c];
@@ -112,8 +127,10 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
 
 int skinny_pick_ksplit(int rows, int N, int K, int groups) {
     const int wgs = cdiv(N, 32) * groups * cdiv(rows > 0 ? rows : 1, 32);
-    int ks = cdiv(512, wgs);                 // aim at ~2 workgroups per CU (256 CUs)
-    const int kmax = K / 64 > 0 ? K / 64 : 1;  // keep >= 64 k per slice (>= 8 MFMAs per wave)
+    int ks = cdiv(K, 4 * KW);                // one chunk per wave: every load in flight at once
+    const int ks_min = cdiv(256, wgs);       // at least one workgroup per CU
+    if (ks < ks_min) ks = ks_min;
+    const int kmax = K / 32 > 0 ? K / 32 : 1;  // keep >= 32 k per slice (>= 4 MFMAs per wave)
     if (ks > kmax) ks = kmax;
     if (ks > SCN_MAX_KSPLIT) ks = SCN_MAX_KSPLIT;
     if (ks < 1) ks = 1;
@@ -126,12 +143,27 @@ int skinny_gemm(hipStream_t st, int rows, int N, int K, int groups, const float*
     SCN_ARG(X && W && Y, "skinny_gemm: null operand");
     SCN_ARG(K >= 1, "skinny_gemm: K must be >= 1");
     SCN_ARG(ksplit >= 1 && ksplit <= SCN_MAX_KSPLIT, "skinny_gemm: ksplit out of range");
-    int kslice = cdiv(K, ksplit);
-    kslice = (kslice + 7) & ~7;
-    if (kslice < 8) kslice = 8;
-    SkinnyArgs a{X, W, Y, ldx, xg, ldw, wg, ldy, yg, yslab, rows, N, K, kslice, groups};
+    SCN_ARG((long)K * ldw * 4 < 0x7fffffffL && (long)rows * ldx * 4 < 0x7fffffffL,
+            "skinny_gemm: operand exceeds the 2 GiB buffer-descriptor range");
+    int per = cdiv(cdiv(K, ksplit), 4);      // k per wave
+    per = (per + 7) & ~7;                    // whole 8-k blocks
+    if (per > KW) per = (per + KW - 1) / KW * KW;   // several full chunks
+    const int nb = per > KW ? NBW : per / 8;
+    const int kslice = 4 * per;
+    const int xvec = (aligned16(X) && ldx % 4 == 0 && xg % 4 == 0 && K % 4 == 0 && K >= 4) ? 1 : 0;
+    SkinnyArgs a{X, W, Y, ldx, xg, ldw, wg, ldy, yg, yslab, rows, N, K, kslice, groups, xvec};
     dim3 grid(cdiv(N, 32) * groups, ksplit, cdiv(rows, 32)), block(256);
-    hipLaunchKernelGGL(skinny_kernel, grid, block, 0, st, a);
+#define SCN_SKINNY_CASE(NB_)                                                                     \
+    case NB_:                                                                                     \
+        if (xvec) hipLaunchKernelGGL((skinny_kernel<NB_, true>), grid, block, 0, st, a);          \
+        else      hipLaunchKernelGGL((skinny_kernel<NB_, false>), grid, block, 0, st, a);         \
+        break;
+    switch (nb) {
+        SCN_SKINNY_CASE(1) SCN_SKINNY_CASE(2) SCN_SKINNY_CASE(3) SCN_SKINNY_CASE(4)
+        SCN_SKINNY_CASE(5) SCN_SKINNY_CASE(6) SCN_SKINNY_CASE(7) SCN_SKINNY_CASE(8)
+        default: SCN_ARG(false, "skinny_gemm: internal blocking error");
+    }
+#undef SCN_SKINNY_CASE
     SCN_LAUNCH_CHECK();
     return 0;
 }

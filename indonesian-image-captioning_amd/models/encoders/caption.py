@@ -9,11 +9,13 @@ import torch
 from torch import nn
 
 from scnattn import functional as SF
-from scnattn.resnet import resnet152_trunk
+from scnattn.resnet import resnet152_trunk, configure_miopen
+
+configure_miopen()
 
 
 class EncoderCaption(nn.Module):
-    def __init__(self, encoded_image_size=14, state_dict_path=None, channels_last=True):
+    def __init__(self, encoded_image_size=14, state_dict_path=None, channels_last=False):
         super().__init__()
         self.enc_image_size = encoded_image_size
         self.resnet = resnet152_trunk()

@@ -43,6 +43,7 @@ class Params(C.Structure):
 _SIGS = {
     "scnattn_version": ([], i32),
     "scnattn_set_option": ([C.c_char_p, i32], i32),
+    "scnattn_profile_collect": ([C.POINTER(C.c_double)], i32),
     "scnattn_seq_workspace": ([C.POINTER(Dims), C.POINTER(sz), C.POINTER(sz)], i32),
     "scnattn_seq_fwd": ([vp, C.POINTER(Dims), C.POINTER(Params), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp], i32),
     "scnattn_seq_bwd": ([vp, C.POINTER(Dims), C.POINTER(Params), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,

@@ -8,8 +8,20 @@ torchvision is not installed in this image (nor on the GPU box), and the referen
 (kaiming-normal fan-out convs, BN gamma=1 beta=0) unless a state_dict is loaded.  On MI355X the
 convolutions run on MIOpen's MFMA kernels through PyTorch-ROCm; channels-last memory format is used so
 the 1x1 convolutions are plain GEMMs over contiguous channels."""
+import os
+
 import torch
 from torch import nn
+
+
+def configure_miopen():
+    """This image ships no gfx950 MIOpen find/kernel database, so MIOpen's default exhaustive find
+    JIT-compiles every applicable solver for each of the ~150 conv configs of ResNet-152 (many minutes on
+    a fresh box).  FAST find mode picks one solver per config from the built-in heuristics (first step
+    ~3 s); measured on MI355X it is also the fastest steady state with NCHW fp32 (50 ms fwd+bwd at B=32
+    vs 320 ms channels-last, 120 ms GEMM-only).  Respect anything the user has already exported."""
+    os.environ.setdefault("MIOPEN_FIND_MODE", "2")
+    os.environ.setdefault("MIOPEN_LOG_LEVEL", "3")
 
 
 class Bottleneck(nn.Module):

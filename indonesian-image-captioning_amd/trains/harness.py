@@ -1,0 +1,120 @@
+"""Synthetic-data training harness: the body of the reference's train step
+(trains/attention_scn.py:204-258, and the pure_scn / pure_attention siblings) with real flags instead
+of module-level globals; defaults equal the reference's constants (:25-61).
+
+One call of ``TrainStep.step()`` =
+    encoder fwd -> decoder fwd -> CrossEntropy over packed tokens + alpha_c * doubly-stochastic term
+    -> zero_grad -> backward (+ bucketed RCCL all-reduce when world > 1) -> clamp +-5 -> Adam.
+Data loading and the ``.item()`` metric syncs of the reference are outside the step.
+Tags are a synthetic input (the tagger encoder is a "next" row of SURVEY.md 8f)."""
+import torch
+from torch import nn
+from torch.nn.utils.rnn import pack_padded_sequence
+
+from models.decoders.attention_scn import AttentionSCN
+from models.decoders.pure_scn import PureSCN
+from models.decoders.pure_attention import PureAttention
+from models.encoders.caption import EncoderCaption
+from scnattn.dp import GradReducer, broadcast_parameters
+from utils.optimizer import FusedClampAdam
+
+DEFAULTS = dict(emb_dim=512, attention_dim=512, decoder_dim=512, factored_dim=512, semantic_dim=1000,
+                dropout=0.5, batch_size=32, encoder_lr=1e-4, decoder_lr=4e-4, grad_clip=5.0, alpha_c=1.0,
+                vocab_size=10000, max_len=50, image_size=256)
+
+
+def synthetic_batch(batch_size, vocab_size, max_len, image_size, semantic_dim, device, seed, ragged=False):
+    """Seeded synthetic inputs of SURVEY.md 8d: images ~ N(0,1); captions <start> + words + <end>
+    padded with 0 to max_len+2 (word-map convention: pad=0, words 1.., unk, start=V-2, end=V-1)."""
+    g = torch.Generator().manual_seed(seed)
+    L = max_len + 2
+    imgs = torch.randn(batch_size, 3, image_size, image_size, generator=g)
+    tags = torch.rand(batch_size, semantic_dim, generator=g)
+    caps = torch.zeros(batch_size, L, dtype=torch.long)
+    lens = torch.full((batch_size,), L, dtype=torch.long)
+    if ragged:
+        lens = torch.randint(7, L + 1, (batch_size,), generator=g)
+    for b in range(batch_size):
+        n = int(lens[b])
+        caps[b, 0] = vocab_size - 2
+        caps[b, 1:n - 1] = torch.randint(1, vocab_size - 3, (n - 2,), generator=g)
+        caps[b, n - 1] = vocab_size - 1
+    return imgs.to(device), tags.to(device), caps.to(device), lens.unsqueeze(1).to(device)
+
+
+def build_decoder(kind, cfg):
+    if kind == "attention_scn":
+        return AttentionSCN(cfg["attention_dim"], cfg["emb_dim"], cfg["decoder_dim"], cfg["factored_dim"],
+                            cfg["semantic_dim"], cfg["vocab_size"], dropout=cfg["dropout"])
+    if kind == "pure_scn":
+        return PureSCN(cfg["emb_dim"], cfg["decoder_dim"], cfg["factored_dim"], cfg["semantic_dim"],
+                       cfg["vocab_size"], dropout=cfg["dropout"])
+    if kind == "pure_attention":
+        return PureAttention(cfg["attention_dim"], cfg["emb_dim"], cfg["decoder_dim"], cfg["vocab_size"],
+                             dropout=cfg["dropout"])
+    raise ValueError("Error model type not found!")
+
+
+class TrainStep:
+    def __init__(self, kind="attention_scn", fine_tune_encoder=True, device="cuda", seed=1234, encoder=True,
+                 bucket_mb=32, **overrides):
+        self.cfg = dict(DEFAULTS)
+        self.cfg.update(overrides)
+        self.kind = kind
+        self.device = torch.device(device)
+        torch.manual_seed(seed)  # same seed on every rank => identical initial weights
+        self.decoder = build_decoder(kind, self.cfg).to(self.device)
+        self.encoder = None
+        self.encoder_optimizer = None
+        if encoder:
+            self.encoder = EncoderCaption().to(self.device)
+            self.encoder.fine_tune(fine_tune_encoder)
+            if fine_tune_encoder:
+                self.encoder_optimizer = FusedClampAdam(
+                    filter(lambda p: p.requires_grad, self.encoder.parameters()), lr=self.cfg["encoder_lr"],
+                    grad_clip=self.cfg["grad_clip"])
+        self.decoder_optimizer = FusedClampAdam(filter(lambda p: p.requires_grad, self.decoder.parameters()),
+                                                lr=self.cfg["decoder_lr"], grad_clip=self.cfg["grad_clip"])
+        self.criterion = nn.CrossEntropyLoss().to(self.device)
+        self.reducers = [GradReducer(self.decoder_optimizer.flat, bucket_mb << 20)]
+        broadcast_parameters(self.decoder_optimizer.flat)
+        if self.encoder_optimizer is not None:
+            self.reducers.append(GradReducer(self.encoder_optimizer.flat, bucket_mb << 20))
+            broadcast_parameters(self.encoder_optimizer.flat)
+        self.decoder.train()
+        if self.encoder is not None:
+            self.encoder.train()   # reference quirk Q3: BN uses batch statistics even when frozen
+
+    def loss_fn(self, scores, caps_sorted, decode_lengths, alphas):
+        targets = caps_sorted[:, 1:]
+        scores = pack_padded_sequence(scores, decode_lengths, batch_first=True).data
+        targets = pack_padded_sequence(targets, decode_lengths, batch_first=True).data
+        loss = self.criterion(scores, targets)
+        if alphas is not None:
+            loss = loss + self.cfg["alpha_c"] * ((1. - alphas.sum(dim=1)) ** 2).mean()
+        return loss
+
+    def step(self, imgs, tags, caps, caplens, encoder_out=None):
+        if self.encoder is not None:
+            encoder_out = self.encoder(imgs)
+        if self.kind == "attention_scn":
+            scores, caps_sorted, decode_lengths, alphas, _ = self.decoder(encoder_out, tags, caps, caplens)
+        elif self.kind == "pure_scn":
+            scores, caps_sorted, decode_lengths, _ = self.decoder(encoder_out, tags, caps, caplens)
+            alphas = None
+        else:
+            scores, caps_sorted, decode_lengths, alphas, _ = self.decoder(encoder_out, caps, caplens)
+        loss = self.loss_fn(scores, caps_sorted, decode_lengths, alphas)
+        self.decoder_optimizer.zero_grad()
+        if self.encoder_optimizer is not None:
+            self.encoder_optimizer.zero_grad()
+        for r in self.reducers:
+            r.reset()
+        loss.backward()
+        scale = 1.0
+        for r in self.reducers:
+            scale = r.finish()
+        self.decoder_optimizer.step(scale)
+        if self.encoder_optimizer is not None:
+            self.encoder_optimizer.step(scale)
+        return loss

@@ -28,53 +28,25 @@ def adjust_learning_rate(optimizer, shrink_factor):
 class FusedClampAdam:
     """Adam(lr, betas, eps) with the reference's element-wise gradient clamp fused in.
 
-    Parameters are re-homed into one flat buffer (``p.data`` becomes a view) and each ``p.grad`` is a
-    view into one flat gradient buffer; ``step(grad_scale)`` first multiplies gradients by
-    ``grad_scale`` (1/world_size after a sum all-reduce)."""
+    Parameters and gradients live in a scnattn.flat.FlatBuffer; ``step(grad_scale)`` first multiplies
+    gradients by ``grad_scale`` (1/world_size after a SUM all-reduce), clamps to +-grad_clip, then
+    applies torch.optim.Adam's update -- one HIP kernel launch for the whole model."""
 
     def __init__(self, params, lr, grad_clip=None, betas=(0.9, 0.999), eps=1e-8):
-        self.params = [p for p in params if p.requires_grad]
-        assert self.params, "FusedClampAdam: no trainable parameters"
-        dev = self.params[0].device
+        from scnattn.flat import FlatBuffer
+        self.flat = FlatBuffer(params)
+        self.params = self.flat.params
         self.param_groups = [{'params': self.params, 'lr': lr}]
         self.grad_clip, self.betas, self.eps = grad_clip, betas, eps
         self.step_count = 0
-        offs, n = [], 0
-        for p in self.params:
-            offs.append(n)
-            n += (p.numel() + 63) // 64 * 64   # 256-byte granules
-        self.numel = n
-        self.flat_p = torch.zeros(n, device=dev, dtype=torch.float32)
-        self.flat_g = torch.zeros(n, device=dev, dtype=torch.float32)
-        self.flat_m = torch.zeros(n, device=dev, dtype=torch.float32)
-        self.flat_v = torch.zeros(n, device=dev, dtype=torch.float32)
-        self.offsets = offs
-        self._gviews = []
-        with torch.no_grad():
-            for p, o in zip(self.params, offs):
-                # keep each tensor's own (dense) stride order, e.g. channels-last conv weights
-                view = self.flat_p[o:o + p.numel()].as_strided(p.shape, p.data.stride())
-                view.copy_(p.data)
-                p.data = view
-                gv = self.flat_g[o:o + p.numel()].as_strided(p.shape, p.data.stride())
-                self._gviews.append(gv)
-                p.grad = gv
+        self.flat_m = torch.zeros_like(self.flat.flat_p)
+        self.flat_v = torch.zeros_like(self.flat.flat_p)
 
     def zero_grad(self, set_to_none=False):
-        self.flat_g.zero_()
-        for p, gv in zip(self.params, self._gviews):
-            p.grad = gv
-
-    def _gather_stray_grads(self):
-        for p, gv in zip(self.params, self._gviews):
-            if p.grad is None:
-                gv.zero_()
-            elif p.grad.data_ptr() != gv.data_ptr():
-                gv.copy_(p.grad)
-            p.grad = gv
+        self.flat.zero_grad()
 
     def step(self, grad_scale=1.0):
-        self._gather_stray_grads()
+        self.flat.gather_stray_grads()
         self.step_count += 1
-        SF.clamp_adam_(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.param_groups[0]['lr'],
+        SF.clamp_adam_(self.flat.flat_p, self.flat.flat_g, self.flat_m, self.flat_v, self.param_groups[0]['lr'],
                        self.step_count, self.grad_clip, self.betas[0], self.betas[1], self.eps, grad_scale)
