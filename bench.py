@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--max-len", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ksplit", type=int, default=0)
+    ap.add_argument("--graph", action="store_true", help="replay the encoder as HIP graphs (measured slower)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -120,7 +121,7 @@ def main():
         SF.set_option("ksplit", args.ksplit)
     fine_tune = not args.no_finetune
     ts = TrainStep(kind=args.workload, fine_tune_encoder=fine_tune, device=dev, encoder=not args.decoder_only,
-                   batch_size=args.batch, max_len=args.max_len)
+                   batch_size=args.batch, max_len=args.max_len, graph_encoder=args.graph)
     cfg = ts.cfg
     imgs, tags, caps, caplens = synthetic_batch(args.batch, cfg["vocab_size"], cfg["max_len"], cfg["image_size"],
                                                 cfg["semantic_dim"], dev, 1234 + rank)

@@ -160,6 +160,20 @@ int scnattn_pool_permute_fwd(void* stream, int B, int C, int Hin, int Win, int H
                              long sxb, long sxc, long sxh, long sxw, float* y);
 int scnattn_pool_permute_bwd(void* stream, int B, int C, int Hin, int Win, int Ho, int Wo, const float* dy,
                              float* dx, long sxb, long sxc, long sxh, long sxw);
+/* Fused BatchNorm2d (+ residual) (+ ReLU) on channels-last maps viewed as [R = N*H*W, C] (C % 4 == 0):
+ * the `bn -> relu` / `bn -> (+identity) -> relu` groups of torchvision's Bottleneck behind
+ * models/encoders/caption.py:17-22.  `partial` needs scnattn_bn_workspace_floats(C) floats.
+ *   bn_stats : batch mean / 1/sqrt(var+eps) per channel (+ running-stat update with `momentum`)
+ *   bn_apply : y = relu?(gamma*(z-mean)*invstd + beta + res?)
+ *   bn_bwd   : dbeta, dgamma, dz (batch-stat form when train != 0) and dres = dy*[y>0] */
+int scnattn_bn_workspace_floats(int C);
+int scnattn_bn_stats(void* stream, int R, int C, const float* x, float eps, float momentum, float* partial,
+                     float* mean, float* invstd, float* run_mean, float* run_var);
+int scnattn_bn_apply(void* stream, int R, int C, const float* z, const float* res, const float* mean,
+                     const float* invstd, const float* gamma, const float* beta, int relu, float* y);
+int scnattn_bn_bwd(void* stream, int R, int C, const float* dy, const float* y, const float* z, const float* mean,
+                   const float* invstd, const float* gamma, int relu, int train, float* partial, float* dbeta,
+                   float* dgamma, float* dz, float* dres);
 /* utils/optimizer.py:1-11 (element-wise clamp) fused with torch.optim.Adam's update
  * (trains/attention_scn.py:244-252); g is first scaled by gscale (1/world for data parallel). */
 int scnattn_clamp_adam(void* stream, long n, float* p, const float* g, float* m, float* v, double lr,

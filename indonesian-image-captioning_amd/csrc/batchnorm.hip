@@ -1,0 +1,339 @@
+// Fused BatchNorm2d (+ residual add) (+ ReLU) for the ResNet-152 trunk, channels-last.
+//
+// The reference's encoder (models/encoders/caption.py:17-22) is torchvision's ResNet-152, whose
+// bottleneck block runs, after every convolution,  bn -> relu  or  bn -> (+identity) -> relu  as
+// separate eager ops; in train mode each BatchNorm is 3 kernels forward and 3 backward, the ReLU and the
+// residual add are one more each way.  On channels-last memory a feature map is a row-major
+// [R = N*H*W, C] matrix, so batch statistics are plain column reductions and everything else is
+// element-wise; these kernels do the whole group in two passes forward and two backward:
+//   forward : bn_stats (column sums, shifted for conditioning) -> bn_finalize (mean, 1/std, running
+//             stats)  ;  bn_apply : y = relu(gamma*(z-mean)/std + beta + residual)
+//   backward: bn_bwd_reduce : dbeta = sum g, dgamma = sum g*xhat with g = dy*[y>0]
+//             bn_bwd_dx     : dz = gamma/std * (g - dbeta/R - xhat*dgamma/R),  dresidual = g
+// All are HBM-bound streaming kernels (16-byte loads along C, 4 independent row loads in flight).
+#include "common.h"
+#include "kernels.h"
+
+namespace scn {
+
+namespace {
+
+// partial[chunk][2][C]: shifted sums S1 = sum(x - s), S2 = sum((x - s)^2), s = x[0][c]
+__global__ __launch_bounds__(256) void bn_stats_kernel(int R, int C, int rows_per_chunk, const float* __restrict__ x,
+                                                       float* __restrict__ partial) {
+    __shared__ float red[16][2][64 + 1];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cl * 4;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    if (c < C) {
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(x + c);
+        int r = r0 + rl;
+        for (; r + 48 < r1; r += 64) {
+            f32x4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4*>(x + (long)(r + 16 * j) * C + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float d = v[j][k] - sh[k];
+                    s1[k] += d;
+                    s2[k] = fmaf(d, d, s2[k]);
+                }
+        }
+        for (; r < r1; r += 16) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (long)r * C + c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float d = v[k] - sh[k];
+                s1[k] += d;
+                s2[k] = fmaf(d, d, s2[k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        red[rl][0][cl * 4 + k] = s1[k];
+        red[rl][1][cl * 4 + k] = s2[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6, cc = threadIdx.x & 63;
+        if (blockIdx.x * 64 + cc < C) {
+            float v = red[0][which][cc];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) v += red[i][which][cc];
+            partial[((long)blockIdx.y * 2 + which) * C + blockIdx.x * 64 + cc] = v;
+        }
+    }
+}
+
+// Sum the per-chunk partials of 16 channels per workgroup: 16 chunk-lanes per channel run in parallel
+// (a serial loop over up to 256 chunks is one dependent memory latency per chunk: ~40 us).
+__device__ __forceinline__ void reduce_partials16(const float* __restrict__ partial, int C, int nchunk, int c, int lane16,
+                                                  float (*red)[2][17], float& s1, float& s2) {
+    float a = 0.f, b = 0.f;
+    if (c < C) {
+#pragma unroll 4
+        for (int i = lane16; i < nchunk; i += 16) {
+            a += partial[((long)i * 2) * C + c];
+            b += partial[((long)i * 2 + 1) * C + c];
+        }
+    }
+    const int cc = threadIdx.x & 15;
+    red[lane16][0][cc] = a;
+    red[lane16][1][cc] = b;
+    __syncthreads();
+    s1 = 0.f;
+    s2 = 0.f;
+    if (lane16 == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            s1 += red[i][0][cc];
+            s2 += red[i][1][cc];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(int R, int C, int nchunk, const float* __restrict__ x,
+                                                          const float* __restrict__ partial, float eps, float momentum,
+                                                          float* __restrict__ mean, float* __restrict__ invstd,
+                                                          float* __restrict__ run_mean, float* __restrict__ run_var) {
+    __shared__ float red[16][2][17];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), lane16 = threadIdx.x >> 4;
+    float s1, s2;
+    reduce_partials16(partial, C, nchunk, c, lane16, red, s1, s2);
+    if (lane16 != 0 || c >= C) return;
+    const float inv_n = 1.f / (float)R;
+    const float m1 = s1 * inv_n;
+    const float mu = x[c] + m1;
+    float var = s2 * inv_n - m1 * m1;
+    if (var < 0.f) var = 0.f;
+    mean[c] = mu;
+    invstd[c] = rsqrtf(var + eps);
+    if (run_mean) run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mu;
+    if (run_var) {
+        const float unbiased = R > 1 ? var * ((float)R / (float)(R - 1)) : var;
+        run_var[c] = (1.f - momentum) * run_var[c] + momentum * unbiased;
+    }
+}
+
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(256) void bn_apply_kernel(long n4, int C, const float* __restrict__ z,
+                                                       const float* __restrict__ res, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ y) {
+    const int C4 = C >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C4) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(z + i * 4);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
+        const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
+        const f32x4 be = *reinterpret_cast<const f32x4*>(beta + c);
+        f32x4 rr = {0.f, 0.f, 0.f, 0.f};
+        if (RES) rr = *reinterpret_cast<const f32x4*>(res + i * 4);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float t = fmaf((v[k] - mu[k]) * is[k], ga[k], be[k]);
+            if (RES) t += rr[k];
+            if (RELU) t = fmaxf(t, 0.f);
+            o[k] = t;
+        }
+        *reinterpret_cast<f32x4*>(y + i * 4) = o;
+    }
+}
+
+// partial[chunk][2][C]: sum g, sum g*xhat, g = dy * [y > 0] (RELU) or dy
+template <bool RELU>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(int R, int C, int rows_per_chunk, const float* __restrict__ dy,
+                                                            const float* __restrict__ y, const float* __restrict__ z,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            float* __restrict__ partial) {
+    __shared__ float red[16][2][64 + 1];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cl * 4;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+    float sg[4] = {0, 0, 0, 0}, sx[4] = {0, 0, 0, 0};
+    if (c < C) {
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
+        const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c);
+        for (int r = r0 + rl; r < r1; r += 32) {
+            f32x4 g[2], yy[2], zz[2];
+            bool ok[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int rr = r + 16 * j;
+                ok[j] = rr < r1;
+                const long off = (long)min(rr, r1 - 1) * C + c;
+                g[j] = *reinterpret_cast<const f32x4*>(dy + off);
+                zz[j] = *reinterpret_cast<const f32x4*>(z + off);
+                if (RELU) yy[j] = *reinterpret_cast<const f32x4*>(y + off);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float gv = g[j][k];
+                    if (RELU && !(yy[j][k] > 0.f)) gv = 0.f;
+                    if (!ok[j]) gv = 0.f;
+                    sg[k] += gv;
+                    sx[k] = fmaf(gv, (zz[j][k] - mu[k]) * is[k], sx[k]);
+                }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        red[rl][0][cl * 4 + k] = sg[k];
+        red[rl][1][cl * 4 + k] = sx[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6, cc = threadIdx.x & 63;
+        if (blockIdx.x * 64 + cc < C) {
+            float v = red[0][which][cc];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) v += red[i][which][cc];
+            partial[((long)blockIdx.y * 2 + which) * C + blockIdx.x * 64 + cc] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int C, int nchunk, const float* __restrict__ partial,
+                                                              float* __restrict__ dbeta, float* __restrict__ dgamma) {
+    __shared__ float red[16][2][17];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), lane16 = threadIdx.x >> 4;
+    float a, b;
+    reduce_partials16(partial, C, nchunk, c, lane16, red, a, b);
+    if (lane16 != 0 || c >= C) return;
+    dbeta[c] = a;
+    dgamma[c] = b;
+}
+
+// TRAIN: dz = gamma*invstd*(g - dbeta/R - xhat*dgamma/R); eval: dz = gamma*invstd*g.  dres = g.
+template <bool RELU, bool TRAIN>
+__global__ __launch_bounds__(256) void bn_bwd_dx_kernel(long n4, int R, int C, const float* __restrict__ dy,
+                                                        const float* __restrict__ y, const float* __restrict__ z,
+                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ dbeta,
+                                                        const float* __restrict__ dgamma, float* __restrict__ dz,
+                                                        float* __restrict__ dres) {
+    const int C4 = C >> 2;
+    const float inv_n = 1.f / (float)R;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C4) * 4;
+        f32x4 g = *reinterpret_cast<const f32x4*>(dy + i * 4);
+        if (RELU) {
+            const f32x4 yy = *reinterpret_cast<const f32x4*>(y + i * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (!(yy[k] > 0.f)) g[k] = 0.f;
+        }
+        const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
+        f32x4 o;
+        if (TRAIN) {
+            const f32x4 zz = *reinterpret_cast<const f32x4*>(z + i * 4);
+            const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
+            const f32x4 db = *reinterpret_cast<const f32x4*>(dbeta + c);
+            const f32x4 dg = *reinterpret_cast<const f32x4*>(dgamma + c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float xh = (zz[k] - mu[k]) * is[k];
+                o[k] = ga[k] * is[k] * (g[k] - db[k] * inv_n - xh * dg[k] * inv_n);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = ga[k] * is[k] * g[k];
+        }
+        if (dz) *reinterpret_cast<f32x4*>(dz + i * 4) = o;
+        if (dres) *reinterpret_cast<f32x4*>(dres + i * 4) = g;
+    }
+}
+
+inline int pick_chunks(int R, int C, int* rows_per_chunk) {
+    const int colgroups = cdiv(C, 64);
+    int nchunk = 2048 / colgroups;           // ~8 workgroups per CU in total
+    const int maxchunk = cdiv(R, 64);        // at least 64 rows per chunk
+    if (nchunk > maxchunk) nchunk = maxchunk;
+    if (nchunk < 1) nchunk = 1;
+    if (nchunk > 256) nchunk = 256;
+    int rpc = cdiv(R, nchunk);
+    rpc = (rpc + 15) & ~15;
+    *rows_per_chunk = rpc;
+    return cdiv(R, rpc);
+}
+
+inline unsigned ew_blocks(long n4) {
+    long b = (n4 + 255) / 256;
+    if (b > 8192) b = 8192;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+int bn_max_chunks() { return 256; }
+
+int bn_stats(hipStream_t st, int R, int C, const float* x, float eps, float momentum, float* partial, float* mean,
+             float* invstd, float* run_mean, float* run_var) {
+    SCN_ARG(R > 0 && C > 0 && C % 4 == 0 && x && partial && mean && invstd, "bn_stats: bad argument");
+    SCN_ARG(aligned16(x), "bn_stats: x must be 16-byte aligned");
+    int rpc;
+    const int nchunk = pick_chunks(R, C, &rpc);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(cdiv(C, 64), nchunk), dim3(256), 0, st, R, C, rpc, x, partial);
+    SCN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, R, C, nchunk, x, partial, eps,
+                       momentum, mean, invstd, run_mean, run_var);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
+int bn_apply(hipStream_t st, int R, int C, const float* z, const float* res, const float* mean, const float* invstd,
+             const float* gamma, const float* beta, int relu, float* y) {
+    SCN_ARG(R > 0 && C > 0 && C % 4 == 0 && z && mean && invstd && gamma && beta && y, "bn_apply: bad argument");
+    const long n4 = (long)R * C / 4;
+    dim3 grid(ew_blocks(n4)), block(256);
+#define SCN_BN_APPLY(RELU_, RES_) \
+    hipLaunchKernelGGL((bn_apply_kernel<RELU_, RES_>), grid, block, 0, st, n4, C, z, res, mean, invstd, gamma, beta, y)
+    if (relu && res) SCN_BN_APPLY(true, true);
+    else if (relu) SCN_BN_APPLY(true, false);
+    else if (res) SCN_BN_APPLY(false, true);
+    else SCN_BN_APPLY(false, false);
+#undef SCN_BN_APPLY
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
+int bn_bwd(hipStream_t st, int R, int C, const float* dy, const float* y, const float* z, const float* mean,
+           const float* invstd, const float* gamma, int relu, int train, float* partial, float* dbeta, float* dgamma,
+           float* dz, float* dres) {
+    SCN_ARG(R > 0 && C > 0 && C % 4 == 0 && dy && z && mean && invstd && gamma && partial && dbeta && dgamma,
+            "bn_bwd: bad argument");
+    SCN_ARG(!relu || y, "bn_bwd: relu needs the forward output");
+    int rpc;
+    const int nchunk = pick_chunks(R, C, &rpc);
+    dim3 rgrid(cdiv(C, 64), nchunk), block(256);
+    if (relu) hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, rgrid, block, 0, st, R, C, rpc, dy, y, z, mean, invstd, partial);
+    else      hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, rgrid, block, 0, st, R, C, rpc, dy, y, z, mean, invstd, partial);
+    SCN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), block, 0, st, C, nchunk, partial, dbeta, dgamma);
+    SCN_LAUNCH_CHECK();
+    if (dz || dres) {
+        const long n4 = (long)R * C / 4;
+        dim3 grid(ew_blocks(n4));
+#define SCN_BN_DX(RELU_, TRAIN_)                                                                                  \
+    hipLaunchKernelGGL((bn_bwd_dx_kernel<RELU_, TRAIN_>), grid, block, 0, st, n4, R, C, dy, y, z, mean, invstd, gamma, \
+                       dbeta, dgamma, dz, dres)
+        if (relu && train) SCN_BN_DX(true, true);
+        else if (relu) SCN_BN_DX(true, false);
+        else if (train) SCN_BN_DX(false, true);
+        else SCN_BN_DX(false, false);
+#undef SCN_BN_DX
+        SCN_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+}  // namespace scn

@@ -13,6 +13,12 @@ int sgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
           const float* B, long ldb, float beta, float* C, long ldc, const float* bias,
           const float* rowmask, int batch, long sA, long sB, long sC);
 
+// same, with a workspace: low-parallelism shapes (few output tiles, deep K) are split along K into
+// partial slabs in `ws` and reduced in slab order by a second launch (deterministic)
+int sgemm_ws(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, const float* A, long lda,
+             const float* B, long ldb, float beta, float* C, long ldc, const float* bias, const float* rowmask,
+             int batch, long sA, long sB, long sC, float* ws, long ws_floats);
+
 // ---- skinny.hip ------------------------------------------------------------------------------
 int skinny_pick_ksplit(int rows, int N, int K, int groups);
 int skinny_gemm(hipStream_t st, int rows, int N, int K, int groups, const float* X, long ldx, long xg,
@@ -81,5 +87,15 @@ int clamp_adam(hipStream_t st, long n, float* p, const float* g, float* m, float
                double b2, double eps, int step, double clip, double gscale);
 int mul_bcast(hipStream_t st, int T, int B, int N, const float* x, const float* q, float* out);
 int reduce_slabs(hipStream_t st, int rows, int N, Slabs s, float* out);
+
+// ---- batchnorm.hip (channels-last feature maps as [R = N*H*W, C] matrices) --------------------------
+int bn_max_chunks();
+int bn_stats(hipStream_t st, int R, int C, const float* x, float eps, float momentum, float* partial, float* mean,
+             float* invstd, float* run_mean, float* run_var);
+int bn_apply(hipStream_t st, int R, int C, const float* z, const float* res, const float* mean, const float* invstd,
+             const float* gamma, const float* beta, int relu, float* y);
+int bn_bwd(hipStream_t st, int R, int C, const float* dy, const float* y, const float* z, const float* mean,
+           const float* invstd, const float* gamma, int relu, int train, float* partial, float* dbeta, float* dgamma,
+           float* dz, float* dres);
 
 }  // namespace scn

@@ -81,13 +81,15 @@ struct Saved {
         *pa_all, *ph_all, *gates_all, *tanhc_all, *Hd_bm, *rowmask;
 };
 
+constexpr long GEMM_WS_FLOATS = 8L << 20;   // 32 MiB of split-K partials for the big GEMMs
+
 struct FwdScratch {
-    float *WcatA, *WD, *slabA, *e, *slabC, *xcat, *slabD;
+    float *WcatA, *WD, *slabA, *e, *slabC, *xcat, *slabD, *gws;
 };
 
 struct BwdScratch {
     float *WDb, *WaTz, *WcatT, *dHd_bm, *dhfc_tm, *dr_all, *dpx_all, *dcat_all, *dawe_all, *de_all, *dalpha, *dc,
-        *dqx_acc, *dqh_acc, *sDb, *sZ, *sH, *datt1, *dwpart, *dwtmp, *demb_tm, *dmean, *dh0, *mx_all;
+        *dqx_acc, *dqh_acc, *sDb, *sZ, *sH, *datt1, *dwpart, *dwtmp, *demb_tm, *dmean, *dh0, *mx_all, *gws;
 };
 
 inline size_t sz(long a, long b = 1, long c = 1, long d = 1) { return (size_t)a * b * c * d; }
@@ -129,6 +131,7 @@ size_t carve_fwd(const scnattn_dims& d, float* base, FwdScratch& s) {
     s.slabC = d.has_att ? c.take(sz(SCN_MAX_KSPLIT, B, 4 * F)) : nullptr;
     s.xcat = c.take(sz(B, 4, 2 * F));
     s.slabD = c.take(sz(SCN_MAX_KSPLIT, 4, B, D));
+    s.gws = c.take(GEMM_WS_FLOATS);
     return c.off * sizeof(float);
 }
 
@@ -159,6 +162,7 @@ size_t carve_bwd(const scnattn_dims& d, float* base, BwdScratch& s) {
     s.dmean = c.take(sz(B, E));
     s.dh0 = c.take(sz(B, D));
     s.mx_all = c.take(sz(T, B, F4));
+    s.gws = c.take(GEMM_WS_FLOATS);
     return c.off * sizeof(float);
 }
 
@@ -236,20 +240,20 @@ int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
 
     // ---- time-invariant pieces -----------------------------------------------------------------
     if (d.has_att)
-        SCN_TRY(sgemm(st, false, true, B * P, A, E, 1.f, enc, E, w->attention_encoder_att_weight, E, 0.f, s.att1, A,
-                      w->attention_encoder_att_bias, nullptr, 1, 0, 0, 0));
-    SCN_TRY(sgemm(st, false, false, B, F4, d.S, 1.f, tags, d.S, w->decode_step_weight_ib, F4, 0.f, s.qx, F4, nullptr,
-                  nullptr, 1, 0, 0, 0));
-    SCN_TRY(sgemm(st, false, false, B, F4, d.S, 1.f, tags, d.S, w->decode_step_weight_hb, F4, 0.f, s.qh, F4, nullptr,
-                  nullptr, 1, 0, 0, 0));
+        SCN_TRY(sgemm_ws(st, false, true, B * P, A, E, 1.f, enc, E, w->attention_encoder_att_weight, E, 0.f, s.att1, A,
+                      w->attention_encoder_att_bias, nullptr, 1, 0, 0, 0, f.gws, GEMM_WS_FLOATS));
+    SCN_TRY(sgemm_ws(st, false, false, B, F4, d.S, 1.f, tags, d.S, w->decode_step_weight_ib, F4, 0.f, s.qx, F4, nullptr,
+                  nullptr, 1, 0, 0, 0, f.gws, GEMM_WS_FLOATS));
+    SCN_TRY(sgemm_ws(st, false, false, B, F4, d.S, 1.f, tags, d.S, w->decode_step_weight_hb, F4, 0.f, s.qh, F4, nullptr,
+                  nullptr, 1, 0, 0, 0, f.gws, GEMM_WS_FLOATS));
     SCN_TRY(gather_rows_tm(st, B, T, d.L, M, (const long long*)caps, w->embedding_weight, d.V, s.emb_tm));
-    SCN_TRY(sgemm(st, false, false, T * B, F4, M, 1.f, s.emb_tm, M, w->decode_step_weight_ia, F4, 0.f, s.ex, F4,
-                  nullptr, nullptr, 1, 0, 0, 0));
+    SCN_TRY(sgemm_ws(st, false, false, T * B, F4, M, 1.f, s.emb_tm, M, w->decode_step_weight_ia, F4, 0.f, s.ex, F4,
+                  nullptr, nullptr, 1, 0, 0, 0, f.gws, GEMM_WS_FLOATS));
     SCN_TRY(mean_pixels(st, B, P, E, enc, s.mean_enc));
-    SCN_TRY(sgemm(st, false, true, B, D, E, 1.f, s.mean_enc, E, w->init_h_weight, E, 0.f, s.Hs, D, w->init_h_bias,
-                  nullptr, 1, 0, 0, 0));
-    SCN_TRY(sgemm(st, false, true, B, D, E, 1.f, s.mean_enc, E, w->init_c_weight, E, 0.f, s.Cs, D, w->init_c_bias,
-                  nullptr, 1, 0, 0, 0));
+    SCN_TRY(sgemm_ws(st, false, true, B, D, E, 1.f, s.mean_enc, E, w->init_h_weight, E, 0.f, s.Hs, D, w->init_h_bias,
+                  nullptr, 1, 0, 0, 0, f.gws, GEMM_WS_FLOATS));
+    SCN_TRY(sgemm_ws(st, false, true, B, D, E, 1.f, s.mean_enc, E, w->init_c_weight, E, 0.f, s.Cs, D, w->init_c_bias,
+                  nullptr, 1, 0, 0, 0, f.gws, GEMM_WS_FLOATS));
 
     // ---- the recurrence --------------------------------------------------------------------------
     const long BD = (long)B * D;
@@ -287,8 +291,8 @@ int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
 
     // ---- dropout + fc over all (b,t) rows at once ------------------------------------------------
     SCN_TRY(hidden_to_bm(st, B, T, D, dl_dev, s.Hs + BD, drop_mask, s.Hd_bm, s.rowmask));
-    SCN_TRY(sgemm(st, false, true, B * T, d.V, D, 1.f, s.Hd_bm, D, w->fc_weight, D, 0.f, preds, d.V, w->fc_bias,
-                  s.rowmask, 1, 0, 0, 0));
+    SCN_TRY(sgemm_ws(st, false, true, B * T, d.V, D, 1.f, s.Hd_bm, D, w->fc_weight, D, 0.f, preds, d.V, w->fc_bias,
+                  s.rowmask, 1, 0, 0, 0, f.gws, GEMM_WS_FLOATS));
     return 0;
 }
 
@@ -310,14 +314,14 @@ int seq_bwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
     carve_bwd(d, scratch, k);
 
     // ---- fc / dropout ----------------------------------------------------------------------------
-    SCN_TRY(sgemm(st, false, false, B * T, D, V, 1.f, dpreds, V, w->fc_weight, D, 0.f, k.dHd_bm, D, nullptr, nullptr, 1,
-                  0, 0, 0));
+    SCN_TRY(sgemm_ws(st, false, false, B * T, D, V, 1.f, dpreds, V, w->fc_weight, D, 0.f, k.dHd_bm, D, nullptr, nullptr, 1,
+                  0, 0, 0, k.gws, GEMM_WS_FLOATS));
     if (g->fc_weight)
-        SCN_TRY(sgemm(st, true, false, V, D, B * T, 1.f, dpreds, V, s.Hd_bm, D, 0.f, g->fc_weight, D, nullptr, nullptr,
-                      1, 0, 0, 0));
+        SCN_TRY(sgemm_ws(st, true, false, V, D, B * T, 1.f, dpreds, V, s.Hd_bm, D, 0.f, g->fc_weight, D, nullptr, nullptr,
+                      1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
     if (g->fc_bias)  // only rows that were decoded carry the bias
-        SCN_TRY(sgemm(st, false, false, 1, V, B * T, 1.f, s.rowmask, B * T, dpreds, V, 0.f, g->fc_bias, V, nullptr,
-                      nullptr, 1, 0, 0, 0));
+        SCN_TRY(sgemm_ws(st, false, false, 1, V, B * T, 1.f, s.rowmask, B * T, dpreds, V, 0.f, g->fc_bias, V, nullptr,
+                      nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
     SCN_TRY(hidden_from_bm(st, B, T, D, dl_dev, k.dHd_bm, drop_mask, k.dhfc_tm));
 
     // ---- transposed weight layouts for the backward contractions ------------------------------------
@@ -374,54 +378,54 @@ int seq_bwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
 
     // ---- weight gradients: one GEMM per weight over the stacked (t,b) rows ---------------------------
     if (g->decode_step_weight_ia) {
-        SCN_TRY(sgemm(st, true, false, M, F4, TB, 1.f, s.emb_tm, M, k.dpx_all, F4, 0.f, g->decode_step_weight_ia, F4,
-                      nullptr, nullptr, 1, 0, 0, 0));
+        SCN_TRY(sgemm_ws(st, true, false, M, F4, TB, 1.f, s.emb_tm, M, k.dpx_all, F4, 0.f, g->decode_step_weight_ia, F4,
+                      nullptr, nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
         if (d.has_att)
-            SCN_TRY(sgemm(st, true, false, E, F4, TB, 1.f, s.z_all, E, k.dpx_all, F4, 0.f,
-                          g->decode_step_weight_ia + (long)M * F4, F4, nullptr, nullptr, 1, 0, 0, 0));
+            SCN_TRY(sgemm_ws(st, true, false, E, F4, TB, 1.f, s.z_all, E, k.dpx_all, F4, 0.f,
+                          g->decode_step_weight_ia + (long)M * F4, F4, nullptr, nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
     }
     if (g->embedding_weight) {
-        SCN_TRY(sgemm(st, false, true, TB, M, F4, 1.f, k.dpx_all, F4, w->decode_step_weight_ia, F4, 0.f, k.demb_tm, M,
-                      nullptr, nullptr, 1, 0, 0, 0));
+        SCN_TRY(sgemm_ws(st, false, true, TB, M, F4, 1.f, k.dpx_all, F4, w->decode_step_weight_ia, F4, 0.f, k.demb_tm, M,
+                      nullptr, nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
         SCN_TRY(scatter_add_rows_tm(st, B, T, d.L, M, (const long long*)caps, dl_dev, k.demb_tm, V,
                                     g->embedding_weight));
     }
     if (g->decode_step_weight_ic) {
         SCN_TRY(mul_bcast(st, T, B, F4, s.pa_all, s.qx, k.mx_all));
-        SCN_TRY(sgemm(st, true, false, D, F, TB, 1.f, k.dr_all, 4 * D, k.mx_all, F4, 0.f, g->decode_step_weight_ic, F4,
-                      nullptr, nullptr, 4, D, F, F));
+        SCN_TRY(sgemm_ws(st, true, false, D, F, TB, 1.f, k.dr_all, 4 * D, k.mx_all, F4, 0.f, g->decode_step_weight_ic, F4,
+                      nullptr, nullptr, 4, D, F, F, k.gws, GEMM_WS_FLOATS));
     }
     if (g->decode_step_weight_hc) {
         SCN_TRY(mul_bcast(st, T, B, F4, s.ph_all, s.qh, k.mx_all));
-        SCN_TRY(sgemm(st, true, false, D, F, TB, 1.f, k.dr_all, 4 * D, k.mx_all, F4, 0.f, g->decode_step_weight_hc, F4,
-                      nullptr, nullptr, 4, D, F, F));
+        SCN_TRY(sgemm_ws(st, true, false, D, F, TB, 1.f, k.dr_all, 4 * D, k.mx_all, F4, 0.f, g->decode_step_weight_hc, F4,
+                      nullptr, nullptr, 4, D, F, F, k.gws, GEMM_WS_FLOATS));
     }
     if (g->decode_step_weight_ha)
-        SCN_TRY(sgemm(st, true, false, D, F4, TB, 1.f, s.Hs, D, k.dcat_all, NC, 0.f, g->decode_step_weight_ha, F4,
-                      nullptr, nullptr, 1, 0, 0, 0));
+        SCN_TRY(sgemm_ws(st, true, false, D, F4, TB, 1.f, s.Hs, D, k.dcat_all, NC, 0.f, g->decode_step_weight_ha, F4,
+                      nullptr, nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
     if (g->decode_step_weight_ib)
-        SCN_TRY(sgemm(st, true, false, d.S, F4, B, 1.f, tags, d.S, k.dqx_acc, F4, 0.f, g->decode_step_weight_ib, F4,
-                      nullptr, nullptr, 1, 0, 0, 0));
+        SCN_TRY(sgemm_ws(st, true, false, d.S, F4, B, 1.f, tags, d.S, k.dqx_acc, F4, 0.f, g->decode_step_weight_ib, F4,
+                      nullptr, nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
     if (g->decode_step_weight_hb)
-        SCN_TRY(sgemm(st, true, false, d.S, F4, B, 1.f, tags, d.S, k.dqh_acc, F4, 0.f, g->decode_step_weight_hb, F4,
-                      nullptr, nullptr, 1, 0, 0, 0));
+        SCN_TRY(sgemm_ws(st, true, false, d.S, F4, B, 1.f, tags, d.S, k.dqh_acc, F4, 0.f, g->decode_step_weight_hb, F4,
+                      nullptr, nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
     if (dtags) {
-        SCN_TRY(sgemm(st, false, true, B, d.S, F4, 1.f, k.dqx_acc, F4, w->decode_step_weight_ib, F4, 0.f, dtags, d.S,
-                      nullptr, nullptr, 1, 0, 0, 0));
-        SCN_TRY(sgemm(st, false, true, B, d.S, F4, 1.f, k.dqh_acc, F4, w->decode_step_weight_hb, F4, 1.f, dtags, d.S,
-                      nullptr, nullptr, 1, 0, 0, 0));
+        SCN_TRY(sgemm_ws(st, false, true, B, d.S, F4, 1.f, k.dqx_acc, F4, w->decode_step_weight_ib, F4, 0.f, dtags, d.S,
+                      nullptr, nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
+        SCN_TRY(sgemm_ws(st, false, true, B, d.S, F4, 1.f, k.dqh_acc, F4, w->decode_step_weight_hb, F4, 1.f, dtags, d.S,
+                      nullptr, nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
     }
     if (g->decode_step_bias_ih) SCN_TRY(colsum(st, TB, 4 * D, k.dr_all, 4 * D, g->decode_step_bias_ih, 0.f));
     if (g->decode_step_bias_hh) SCN_TRY(colsum(st, TB, 4 * D, k.dr_all, 4 * D, g->decode_step_bias_hh, 0.f));
 
     if (d.has_att) {
         if (g->f_beta_weight)
-            SCN_TRY(sgemm(st, true, false, E, D, TB, 1.f, k.dcat_all + F4, NC, s.Hs, D, 0.f, g->f_beta_weight, D,
-                          nullptr, nullptr, 1, 0, 0, 0));
+            SCN_TRY(sgemm_ws(st, true, false, E, D, TB, 1.f, k.dcat_all + F4, NC, s.Hs, D, 0.f, g->f_beta_weight, D,
+                          nullptr, nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
         if (g->f_beta_bias) SCN_TRY(colsum(st, TB, E, k.dcat_all + F4, NC, g->f_beta_bias, 0.f));
         if (g->attention_decoder_att_weight)
-            SCN_TRY(sgemm(st, true, false, A, D, TB, 1.f, k.dcat_all + F4 + E, NC, s.Hs, D, 0.f,
-                          g->attention_decoder_att_weight, D, nullptr, nullptr, 1, 0, 0, 0));
+            SCN_TRY(sgemm_ws(st, true, false, A, D, TB, 1.f, k.dcat_all + F4 + E, NC, s.Hs, D, 0.f,
+                          g->attention_decoder_att_weight, D, nullptr, nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
         if (g->attention_decoder_att_bias)
             SCN_TRY(colsum(st, TB, A, k.dcat_all + F4 + E, NC, g->attention_decoder_att_bias, 0.f));
         int nblk = 0;
@@ -432,37 +436,37 @@ int seq_bwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
             SCN_TRY(copy2d(st, 1, A, k.dwtmp, A + 1, g->attention_full_att_weight, A));
         if (g->attention_full_att_bias) SCN_TRY(copy2d(st, 1, 1, k.dwtmp + A, 1, g->attention_full_att_bias, 1));
         if (g->attention_encoder_att_weight)
-            SCN_TRY(sgemm(st, true, false, A, E, B * P, 1.f, k.datt1, A, enc, E, 0.f, g->attention_encoder_att_weight,
-                          E, nullptr, nullptr, 1, 0, 0, 0));
+            SCN_TRY(sgemm_ws(st, true, false, A, E, B * P, 1.f, k.datt1, A, enc, E, 0.f, g->attention_encoder_att_weight,
+                          E, nullptr, nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
         if (g->attention_encoder_att_bias)
             SCN_TRY(colsum(st, B * P, A, k.datt1, A, g->attention_encoder_att_bias, 0.f));
     }
 
     // ---- initial state (attention_scn.py:82-93) -----------------------------------------------------
     if (g->init_h_weight)
-        SCN_TRY(sgemm(st, true, false, D, E, B, 1.f, k.dh0, D, s.mean_enc, E, 0.f, g->init_h_weight, E, nullptr,
-                      nullptr, 1, 0, 0, 0));
+        SCN_TRY(sgemm_ws(st, true, false, D, E, B, 1.f, k.dh0, D, s.mean_enc, E, 0.f, g->init_h_weight, E, nullptr,
+                      nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
     if (g->init_h_bias) SCN_TRY(colsum(st, B, D, k.dh0, D, g->init_h_bias, 0.f));
     if (g->init_c_weight)
-        SCN_TRY(sgemm(st, true, false, D, E, B, 1.f, k.dc, D, s.mean_enc, E, 0.f, g->init_c_weight, E, nullptr, nullptr,
-                      1, 0, 0, 0));
+        SCN_TRY(sgemm_ws(st, true, false, D, E, B, 1.f, k.dc, D, s.mean_enc, E, 0.f, g->init_c_weight, E, nullptr, nullptr,
+                      1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
     if (g->init_c_bias) SCN_TRY(colsum(st, B, D, k.dc, D, g->init_c_bias, 0.f));
 
     // ---- d loss / d encoder_out (only when the encoder is fine-tuned) -------------------------------
     if (denc) {
         if (d.has_att) {
-            SCN_TRY(sgemm(st, false, false, B * P, E, A, 1.f, k.datt1, A, w->attention_encoder_att_weight, E, 0.f,
-                          denc, E, nullptr, nullptr, 1, 0, 0, 0));
+            SCN_TRY(sgemm_ws(st, false, false, B * P, E, A, 1.f, k.datt1, A, w->attention_encoder_att_weight, E, 0.f,
+                          denc, E, nullptr, nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
             // denc[b] += alpha_b^T (P x T) . dawe_b (T x E), batched over b
-            SCN_TRY(sgemm(st, true, false, P, E, T, 1.f, s.alpha_tm, (long)B * P, k.dawe_all, (long)B * E, 1.f, denc, E,
-                          nullptr, nullptr, B, P, E, (long)P * E));
+            SCN_TRY(sgemm_ws(st, true, false, P, E, T, 1.f, s.alpha_tm, (long)B * P, k.dawe_all, (long)B * E, 1.f, denc, E,
+                          nullptr, nullptr, B, P, E, (long)P * E, k.gws, GEMM_WS_FLOATS));
         } else {
             SCN_HIP(hipMemsetAsync(denc, 0, sizeof(float) * B * P * E, st));
         }
-        SCN_TRY(sgemm(st, false, false, B, E, D, 1.f, k.dh0, D, w->init_h_weight, E, 0.f, k.dmean, E, nullptr, nullptr,
-                      1, 0, 0, 0));
-        SCN_TRY(sgemm(st, false, false, B, E, D, 1.f, k.dc, D, w->init_c_weight, E, 1.f, k.dmean, E, nullptr, nullptr,
-                      1, 0, 0, 0));
+        SCN_TRY(sgemm_ws(st, false, false, B, E, D, 1.f, k.dh0, D, w->init_h_weight, E, 0.f, k.dmean, E, nullptr, nullptr,
+                      1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
+        SCN_TRY(sgemm_ws(st, false, false, B, E, D, 1.f, k.dc, D, w->init_c_weight, E, 1.f, k.dmean, E, nullptr, nullptr,
+                      1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
         SCN_TRY(add_bcast_rows(st, B, P, E, k.dmean, 1.f / (float)P, denc));
     }
     return 0;

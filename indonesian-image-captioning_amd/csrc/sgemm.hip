@@ -27,6 +27,8 @@ struct GemmArgs {
     long lda, ldb, ldc, sA, sB, sC;
     int M, N, K;
     float alpha, beta;
+    int S, kper;      // split-K: S slices of kper (multiple of BK) k each; S == 1 -> direct epilogue
+    float* ws;        // [batch][S][M][N] partial sums when S > 1
 };
 
 // Load a (128 x 16) operand tile into registers.  CONTIG_K: element (r,k) at base[r*ld + k]
@@ -78,9 +80,11 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const float* A = g.A + (long)blockIdx.z * g.sA;
-    const float* B = g.B + (long)blockIdx.z * g.sB;
-    float* C = g.C + (long)blockIdx.z * g.sC;
+    const int zb = blockIdx.z / g.S, sp = blockIdx.z - zb * g.S;
+    const float* A = g.A + (long)zb * g.sA;
+    const float* B = g.B + (long)zb * g.sB;
+    float* C = g.C + (long)zb * g.sC;
+    const int kbeg = sp * g.kper, Kend = min(g.K, kbeg + g.kper);
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -91,12 +95,12 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float ra[2][4], rb[2][4];
-    const int nk = (g.K + BK - 1) / BK;
+    const int nk = max(0, (Kend - kbeg + BK - 1) / BK);
     // descriptors from wave-uniform values (kernel args + blockIdx.z); sizes checked on the host
     const __amdgpu_buffer_rsrc_t ars = make_rsrc(A, (unsigned)((TA ? ((long)(g.K - 1) * g.lda + g.M) : ((long)(g.M - 1) * g.lda + g.K)) * 4));
     const __amdgpu_buffer_rsrc_t brs = make_rsrc(B, (unsigned)((TB ? ((long)(g.N - 1) * g.ldb + g.K) : ((long)(g.K - 1) * g.ldb + g.N)) * 4));
-    load_tile<!TA, VEC>(ars, g.lda, m0, 0, g.M, g.K, tid, ra);
-    load_tile<TB, VEC>(brs, g.ldb, n0, 0, g.N, g.K, tid, rb);
+    load_tile<!TA, VEC>(ars, g.lda, m0, kbeg, g.M, Kend, tid, ra);
+    load_tile<TB, VEC>(brs, g.ldb, n0, kbeg, g.N, Kend, tid, rb);
     store_tile<!TA>(As[0], tid, ra);
     store_tile<TB>(Bs[0], tid, rb);
     __syncthreads();
@@ -105,8 +109,8 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmArgs g) {
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
-            load_tile<!TA, VEC>(ars, g.lda, m0, (kt + 1) * BK, g.M, g.K, tid, ra);
-            load_tile<TB, VEC>(brs, g.ldb, n0, (kt + 1) * BK, g.N, g.K, tid, rb);
+            load_tile<!TA, VEC>(ars, g.lda, m0, kbeg + (kt + 1) * BK, g.M, Kend, tid, ra);
+            load_tile<TB, VEC>(brs, g.ldb, n0, kbeg + (kt + 1) * BK, g.N, Kend, tid, rb);
         }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
@@ -127,6 +131,22 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmArgs g) {
             store_tile<TB>(Bs[cur ^ 1], tid, rb);
         }
         __syncthreads();
+    }
+
+    if (g.S > 1) {   // split-K: raw alpha-scaled partial tile; splitk_reduce_kernel applies the epilogue
+        float* W = g.ws + ((long)blockIdx.z * g.M) * g.N;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 64 + i * 32 + mfma32_row(r, lane);
+                    if (n < g.N && m < g.M) W[(long)m * g.N + n] = g.alpha * acc[i][j][r];
+                }
+            }
+        return;
     }
 
     // Epilogue.  The optional reads (beta*C, rowmask) are issued as one batch of range-checked buffer
@@ -173,11 +193,26 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmArgs g) {
         }
 }
 
+// C = sum_s ws[z][s] + beta*C + bias, rows with rowmask == 0 -> 0 (slab order fixed: deterministic)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)g.M * g.N) return;
+    const int m = (int)(i / g.N), n = (int)(i - (long)m * g.N);
+    const int zb = blockIdx.y;
+    const float* W = g.ws + ((long)zb * g.S) * g.M * g.N;
+    float v = slab_sum(W, i, g.S, (long)g.M * g.N);
+    float* cp = g.C + (long)zb * g.sC + (long)m * g.ldc + n;
+    if (g.bias) v += g.bias[n];
+    if (g.beta != 0.f) v += g.beta * (*cp);
+    if (g.rowmask && g.rowmask[m] == 0.f) v = 0.f;
+    *cp = v;
+}
+
 }  // namespace
 
-int sgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, const float* A, long lda,
-          const float* B, long ldb, float beta, float* C, long ldc, const float* bias,
-          const float* rowmask, int batch, long sA, long sB, long sC) {
+int sgemm_ws(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, const float* A, long lda,
+             const float* B, long ldb, float beta, float* C, long ldc, const float* bias, const float* rowmask,
+             int batch, long sA, long sB, long sC, float* ws, long ws_floats) {
     if (M <= 0 || N <= 0 || batch <= 0) return 0;
     SCN_ARG(A && B && C, "sgemm: null operand");
     SCN_ARG(K >= 1, "sgemm: K must be >= 1");
@@ -187,12 +222,26 @@ int sgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
         SCN_ARG(abytes < 0x7fffffffL && bbytes < 0x7fffffffL, "sgemm: operand exceeds the 2 GiB buffer-descriptor range");
     }
     SCN_ARG(beta == 0.f || ((long)(M - 1) * ldc + N) * 4 < 0x7fffffffL, "sgemm: C too large for beta != 0");
-    GemmArgs g{A, B, C, bias, rowmask, lda, ldb, ldc, sA, sB, sC, M, N, K, alpha, beta};
+    // split-K when the tile grid alone cannot fill the chip and K is deep enough to amortise the reduce
+    const long tiles = (long)cdiv(N, BN) * cdiv(M, BM) * batch;
+    int S = 1;
+    if (ws && tiles < 192 && K >= 1024) {
+        S = (int)((384 + tiles - 1) / tiles);
+        const int smax = K / 512;
+        if (S > smax) S = smax;
+        if (S > SCN_MAX_KSPLIT) S = SCN_MAX_KSPLIT;
+        while (S > 1 && (long)S * batch * M * N > ws_floats) --S;
+        if (S < 1) S = 1;
+    }
+    int kper = cdiv(K, S);
+    kper = (kper + BK - 1) / BK * BK;
+    S = cdiv(K, kper);
+    GemmArgs g{A, B, C, bias, rowmask, lda, ldb, ldc, sA, sB, sC, M, N, K, alpha, beta, S, kper, ws};
     // 16-byte loads need: aligned bases/strides and the contiguous extent a multiple of 4
     const int contigA = tA ? M : K, contigB = tB ? K : N;
     const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0) && (sA % 4 == 0) &&
                      (sB % 4 == 0) && (contigA % 4 == 0) && (contigB % 4 == 0);
-    dim3 grid(cdiv(N, BN), cdiv(M, BM), batch), block(256);
+    dim3 grid(cdiv(N, BN), cdiv(M, BM), batch * S), block(256);
 #define SCN_GEMM_LAUNCH(TA_, TB_)                                                        \
     do {                                                                                 \
         if (vec) hipLaunchKernelGGL((sgemm_kernel<TA_, TB_, true>), grid, block, 0, st, g);  \
@@ -204,7 +253,18 @@ int sgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
     else SCN_GEMM_LAUNCH(true, true);
 #undef SCN_GEMM_LAUNCH
     SCN_LAUNCH_CHECK();
+    if (S > 1) {
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv((long)M * N, 256), batch), dim3(256), 0, st, g);
+        SCN_LAUNCH_CHECK();
+    }
     return 0;
+}
+
+int sgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, const float* A, long lda,
+          const float* B, long ldb, float beta, float* C, long ldc, const float* bias,
+          const float* rowmask, int batch, long sA, long sB, long sC) {
+    return sgemm_ws(st, tA, tB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, rowmask, batch, sA, sB, sC,
+                    nullptr, 0);
 }
 
 }  // namespace scn

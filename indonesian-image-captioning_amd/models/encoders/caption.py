@@ -9,7 +9,7 @@ import torch
 from torch import nn
 
 from scnattn import functional as SF
-from scnattn.resnet import resnet152_trunk, configure_miopen
+from scnattn.resnet import resnet152_trunk, configure_miopen, manage_bn_counters
 
 configure_miopen()
 
@@ -30,6 +30,12 @@ class EncoderCaption(nn.Module):
     def forward(self, images):
         if self.channels_last and images.is_cuda:
             images = images.contiguous(memory_format=torch.channels_last)
+        if images.is_cuda and self.training:
+            flat = getattr(self, "_bn_counters", None)
+            if flat is None or flat.device != images.device:
+                self._bn_counters = flat = manage_bn_counters(self.resnet)
+            if flat is not None:
+                flat.add_(1)     # all BatchNorm num_batches_tracked counters, one launch
         out = self.resnet(images)
         return SF.pool_permute(out, self.enc_image_size)
 

@@ -43,10 +43,6 @@ class GradReducer:
         def hook(param):
             if not self.enabled:
                 return
-            gv = self.flat.gviews[i]
-            if param.grad is not None and param.grad.data_ptr() != gv.data_ptr():
-                gv.copy_(param.grad)      # autograd replaced the view: copy into the flat buffer
-                param.grad = gv
             b = self.bucket_of[i]
             self.pending[b] -= 1
             if self.pending[b] == 0:
@@ -54,7 +50,8 @@ class GradReducer:
         return hook
 
     def _launch(self, b):
-        s, e, _ = self.buckets[b]
+        s, e, idxs = self.buckets[b]
+        self.flat.gather(idxs)            # one multi-tensor copy of the bucket's gradients
         self.works.append(dist.all_reduce(self.flat.flat_g[s:e], op=dist.ReduceOp.SUM, group=self.group,
                                           async_op=True))
         self.launched[b] = True
@@ -72,7 +69,7 @@ class GradReducer:
             return 1.0
         for b in range(len(self.buckets)):
             if not self.launched[b]:
-                self._launch(b)
+                self._launch(b)           # parameters whose hooks never fired are reduced as zeros
         for w in self.works:
             w.wait()
         self.works = []

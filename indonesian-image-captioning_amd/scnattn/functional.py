@@ -378,6 +378,69 @@ def pool_permute(x, out_size):
 
 
 # ----------------------------------------------------------------------------------------------
+# fused BatchNorm2d (+ residual) (+ ReLU), channels-last  (csrc/batchnorm.hip)
+# ----------------------------------------------------------------------------------------------
+_bn_ws = {}
+
+
+def _bn_workspace(dev, C):
+    need = _lib.lib().scnattn_bn_workspace_floats(C)
+    ws = _bn_ws.get(dev)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 20), device=dev, dtype=torch.float32)
+        _bn_ws[dev] = ws    # stream-ordered reuse: every BN call on the device runs on the current stream
+    return ws
+
+
+class _BNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, res, gamma, beta, run_mean, run_var, training, momentum, eps, relu):
+        require_cuda(z, res, gamma, beta)
+        if z.dtype != torch.float32:
+            z = z.float()
+        z = z.contiguous(memory_format=torch.channels_last)
+        if res is not None:
+            res = res.float().contiguous(memory_format=torch.channels_last)
+        N, Cn, H, W = z.shape
+        R = N * H * W
+        st = stream_of(z)
+        gamma, beta = f32c(gamma.detach()), f32c(beta.detach())
+        if training:
+            mean = torch.empty(Cn, device=z.device, dtype=torch.float32)
+            invstd = torch.empty(Cn, device=z.device, dtype=torch.float32)
+            call("scnattn_bn_stats", st, R, Cn, ptr(z), eps, momentum, ptr(_bn_workspace(z.device, Cn)), ptr(mean),
+                 ptr(invstd), ptr(run_mean), ptr(run_var))
+        else:
+            mean, invstd = run_mean.float(), torch.rsqrt(run_var.float() + eps)
+        y = torch.empty_like(z, memory_format=torch.channels_last)
+        call("scnattn_bn_apply", st, R, Cn, ptr(z), ptr(res), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
+             int(relu), ptr(y))
+        ctx.save_for_backward(z, y if relu else None, mean, invstd, gamma)
+        ctx.cfg = (bool(training), bool(relu), res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, y, mean, invstd, gamma = ctx.saved_tensors
+        training, relu, has_res = ctx.cfg
+        N, Cn, H, W = z.shape
+        R = N * H * W
+        dy = dy.float().contiguous(memory_format=torch.channels_last)
+        need = ctx.needs_input_grad
+        dz = torch.empty_like(z, memory_format=torch.channels_last) if need[0] else None
+        dres = torch.empty_like(z, memory_format=torch.channels_last) if (has_res and need[1]) else None
+        dbeta = torch.empty(Cn, device=z.device, dtype=torch.float32)
+        dgamma = torch.empty(Cn, device=z.device, dtype=torch.float32)
+        call("scnattn_bn_bwd", stream_of(z), R, Cn, ptr(dy), ptr(y), ptr(z), ptr(mean), ptr(invstd), ptr(gamma),
+             int(relu), int(training), ptr(_bn_workspace(z.device, Cn)), ptr(dbeta), ptr(dgamma), ptr(dz), ptr(dres))
+        return (dz, dres, dgamma if need[2] else None, dbeta if need[3] else None, None, None, None, None, None, None)
+
+
+def bn_act(z, res, gamma, beta, run_mean, run_var, training, momentum, eps, relu):
+    return _BNAct.apply(z, res, gamma, beta, run_mean, run_var, training, momentum, eps, relu)
+
+
+# ----------------------------------------------------------------------------------------------
 def clamp_adam_(p, g, m, v, lr, step, clip, beta1=0.9, beta2=0.999, eps=1e-8, gscale=1.0):
     """Fused clamp(+-clip) + Adam on flat fp32 buffers (utils/optimizer.py:1-11 + torch.optim.Adam)."""
     require_cuda(p, g, m, v)

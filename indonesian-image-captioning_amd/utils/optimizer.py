@@ -46,7 +46,7 @@ class FusedClampAdam:
         self.flat.zero_grad()
 
     def step(self, grad_scale=1.0):
-        self.flat.gather_stray_grads()
+        self.flat.gather()
         self.step_count += 1
         SF.clamp_adam_(self.flat.flat_p, self.flat.flat_g, self.flat_m, self.flat_v, self.param_groups[0]['lr'],
                        self.step_count, self.grad_clip, self.betas[0], self.betas[1], self.eps, grad_scale)

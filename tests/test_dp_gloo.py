@@ -62,7 +62,7 @@ def _worker(rank, world, port, q):
             fired_in_backward = sum(red.launched)
             scale = red.finish()
         for p, gv in zip(flat.params, flat.gviews):
-            assert p.grad.data_ptr() == gv.data_ptr()
+            assert p.grad.data_ptr() == gv.data_ptr()      # after finish() every .grad is the flat view
             assert p.data_ptr() >= flat.flat_p.data_ptr()
         q.put((rank, flat.flat_g.clone() * scale, flat.flat_p.clone(), fired_in_backward, len(red.buckets)))
     finally:
@@ -91,6 +91,7 @@ def test_two_rank_gradients_equal_single_process():
     x, y = _data()
     flat.zero_grad()
     ((m(x) - y) ** 2).mean().backward()
+    flat.gather()
     for rank, g, p, fired, nb in res:
         assert torch.allclose(g, flat.flat_g, atol=1e-6, rtol=1e-5), "rank %d gradient differs" % rank
         assert torch.equal(p, flat.flat_p), "rank %d parameters differ after broadcast" % rank
@@ -110,12 +111,15 @@ def test_single_process_reducer_is_a_noop():
     x, y = _data()
     flat.zero_grad(); red.reset()
     ((m(x) - y) ** 2).mean().backward()
-    assert red.finish() == 1.0 and flat.flat_g.abs().sum().item() > 0
-    # stray .grad tensors (e.g. foreign zero_grad(set_to_none=True)) are gathered back
-    for p in m.parameters():
-        p.grad = None
-    ((m(x) - y) ** 2).mean().backward()
+    assert red.finish() == 1.0
+    flat.gather()
+    assert flat.flat_g.abs().sum().item() > 0
     keep = flat.flat_g.clone()
-    flat.flat_g.zero_()
-    flat.gather_stray_grads()
-    assert torch.allclose(flat.flat_g, keep)
+    # a second backward without zero_grad accumulates into the flat views (autograd's in-place add)
+    ((m(x) - y) ** 2).mean().backward()
+    flat.gather()
+    assert torch.allclose(flat.flat_g, 2 * keep, atol=1e-6)
+    # parameters that got no gradient are gathered as zeros
+    flat.zero_grad()
+    flat.gather()
+    assert flat.flat_g.abs().sum().item() == 0.0

@@ -8,6 +8,7 @@ from models.encoders.caption import EncoderCaption
 cl = os.environ.get("PROBE_CL", "1") == "1"
 B = int(os.environ.get("PROBE_B", "32"))
 dev = torch.device("cuda:0")
+torch.backends.cudnn.benchmark = os.environ.get("PROBE_BENCH", "0") == "1"
 t0 = time.time()
 enc = EncoderCaption(channels_last=cl).to(dev)
 enc.fine_tune(True); enc.train()
