@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--max-len", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ksplit", type=int, default=0)
+    ap.add_argument("--with-tagger", action="store_true",
+                    help="also run the frozen EncoderTagger ResNet-152 each step (the reference's real step)")
+    ap.add_argument("--forward-only", action="store_true", help="diagnostics: decoder forward only (PMC passes)")
     ap.add_argument("--graph", action="store_true", help="replay the encoder as HIP graphs (measured slower)")
     args = ap.parse_args()
 
@@ -121,7 +124,7 @@ def main():
         SF.set_option("ksplit", args.ksplit)
     fine_tune = not args.no_finetune
     ts = TrainStep(kind=args.workload, fine_tune_encoder=fine_tune, device=dev, encoder=not args.decoder_only,
-                   batch_size=args.batch, max_len=args.max_len, graph_encoder=args.graph)
+                   batch_size=args.batch, max_len=args.max_len, graph_encoder=args.graph, tagger=args.with_tagger)
     cfg = ts.cfg
     imgs, tags, caps, caplens = synthetic_batch(args.batch, cfg["vocab_size"], cfg["max_len"], cfg["image_size"],
                                                 cfg["semantic_dim"], dev, 1234 + rank)
@@ -131,7 +134,11 @@ def main():
 
     def run(n):
         for _ in range(n):
-            ts.step(imgs, tags, caps, caplens, enc_in)
+            if args.forward_only:
+                with torch.no_grad():
+                    ts.decoder(enc_in, tags, caps, caplens)
+            else:
+                ts.step(imgs, tags, caps, caplens, enc_in)
 
     run(args.warmup)
     SF.set_option("profile", 1)
@@ -169,15 +176,23 @@ def main():
                                    "256x256 images, fp32" % (args.workload, cfg["vocab_size"], T,
                                                              " decoder only" if args.decoder_only else
                                                              (" + ResNet-152 fine-tune" if fine_tune
-                                                              else " + frozen ResNet-152"), args.batch),
+                                                              else " + frozen ResNet-152") +
+                                                             (" + tagger ResNet-152" if args.with_tagger else
+                                                              ", synthetic tags"), args.batch),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world},
         }
         if args.workload == "attention_scn" and prof[1] > 0:
             step_us = 1e3 * prof[0] / prof[1]
             ab = step_bytes(cfg, args.batch)
             ach = ab / (step_us * 1e-6) / 1e9
+            traffic, tsrc = None, None
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_decode_step_fwd.json")
+            if args.batch == 32 and os.path.exists(pmc):   # PMC passes cannot run inside this process;
+                with open(pmc) as fh:                        # the committed rocprofv3 result is quoted
+                    traffic = json.load(fh).get("hbm_bytes_per_step")
+                tsrc = "profiles/r01_pmc_decode_step_fwd.json (separate rocprofv3 --pmc passes)"
             out["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
                                "kernel": "decode step fwd = skinny_kernel x3 + attn_scores + attn_context + "
                                          "scn_mix_fwd + lstm_fwd (the fused SCN-cell+attention step)",
                                "algorithmic_bytes_per_step": ab, "avg_step_us": round(step_us, 2),

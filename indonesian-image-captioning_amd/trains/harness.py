@@ -15,6 +15,7 @@ from models.decoders.attention_scn import AttentionSCN
 from models.decoders.pure_scn import PureSCN
 from models.decoders.pure_attention import PureAttention
 from models.encoders.caption import EncoderCaption
+from models.encoders.tagger import EncoderTagger
 from scnattn.dp import GradReducer, broadcast_parameters
 from utils.optimizer import FusedClampAdam
 
@@ -57,7 +58,7 @@ def build_decoder(kind, cfg):
 
 class TrainStep:
     def __init__(self, kind="attention_scn", fine_tune_encoder=True, device="cuda", seed=1234, encoder=True,
-                 bucket_mb=32, graph_encoder=False, **overrides):
+                 bucket_mb=32, graph_encoder=False, tagger=False, **overrides):
         self.cfg = dict(DEFAULTS)
         self.cfg.update(overrides)
         self.kind = kind
@@ -77,6 +78,13 @@ class TrainStep:
                 self.encoder_optimizer = FusedClampAdam(
                     filter(lambda p: p.requires_grad, self.encoder.parameters()), lr=self.cfg["encoder_lr"],
                     grad_clip=self.cfg["grad_clip"])
+        # the reference's real step also runs a frozen tagger ResNet-152 in train() mode to produce the tags
+        # (trains/attention_scn.py:79-81, 194, 214); the benchmark feeds synthetic tags unless tagger=True
+        self.tagger = None
+        if tagger:
+            self.tagger = EncoderTagger(semantic_size=self.cfg["semantic_dim"], channels_last=True).to(self.device)
+            self.tagger.fine_tune(False)
+            self.tagger.train()
         self.decoder_optimizer = FusedClampAdam(filter(lambda p: p.requires_grad, self.decoder.parameters()),
                                                 lr=self.cfg["decoder_lr"], grad_clip=self.cfg["grad_clip"])
         self.criterion = nn.CrossEntropyLoss().to(self.device)
@@ -109,6 +117,8 @@ class TrainStep:
     def step(self, imgs, tags, caps, caplens, encoder_out=None):
         if self.encoder is not None:
             encoder_out = self.encoder_call(imgs)
+        if self.tagger is not None:
+            tags = self.tagger(imgs)
         if self.kind == "attention_scn":
             scores, caps_sorted, decode_lengths, alphas, _ = self.decoder(encoder_out, tags, caps, caplens)
         elif self.kind == "pure_scn":

@@ -151,6 +151,18 @@ def test_encoder_structure_matches_torchvision_resnet152_layout():
     assert enc.enc_image_size == 14 and isinstance(enc.adaptive_pool, torch.nn.AdaptiveAvgPool2d)
 
 
+def test_tagger_structure():
+    from models.encoders.tagger import EncoderTagger
+    t = EncoderTagger()
+    sd = t.state_dict()
+    assert "linear.weight" in sd and sd["linear.weight"].shape == (1000, 2048) and "resnet.7.2.conv3.weight" in sd
+    assert isinstance(list(t.resnet.children())[-1], torch.nn.AdaptiveAvgPool2d)
+    assert abs(t.dropout.p - 0.15) < 1e-12
+    t.fine_tune(False)
+    assert not any(p.requires_grad for p in t.resnet.parameters())
+    assert all(p.requires_grad for p in t.linear.parameters())   # the reference leaves the head trainable
+
+
 def test_encoder_trunk_matches_independent_resnet_definition():
     """Numerical cross-check of our ResNet trunk against HuggingFace's ResNetModel (same v1.5 bottleneck
     topology, built from a local config object: no download) with OUR weights copied in by name.
