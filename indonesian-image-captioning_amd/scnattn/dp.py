@@ -18,7 +18,7 @@ class GradReducer:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.buckets = []      # (start, end, [param indices])
-        start, idxs, limit = 0, [], bucket_bytes // 4
+        start, idxs, limit = 0, [], max(1, bucket_bytes // 4)
         for i, (p, o) in enumerate(zip(flat.params, flat.offsets)):
             idxs.append(i)
             end = o + (p.numel() + 63) // 64 * 64

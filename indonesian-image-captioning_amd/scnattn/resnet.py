@@ -31,9 +31,10 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
     CPU tensors (structure tests) take torch's own ops."""
 
     counter_managed = False   # True: the trunk bumps all num_batches_tracked counters with one add
+    use_fused = True          # class-wide switch (tests compare the fused kernels with torch's own ops)
 
     def forward(self, x, residual=None, relu=False):
-        if not x.is_cuda or self.weight is None or not self.track_running_stats or self.momentum is None:
+        if not x.is_cuda or not FusedBatchNorm2d.use_fused or self.weight is None or not self.track_running_stats or self.momentum is None:
             y = super().forward(x)
             if residual is not None:
                 y = y + residual

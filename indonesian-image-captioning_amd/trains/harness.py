@@ -88,10 +88,10 @@ class TrainStep:
         self.decoder_optimizer = FusedClampAdam(filter(lambda p: p.requires_grad, self.decoder.parameters()),
                                                 lr=self.cfg["decoder_lr"], grad_clip=self.cfg["grad_clip"])
         self.criterion = nn.CrossEntropyLoss().to(self.device)
-        self.reducers = [GradReducer(self.decoder_optimizer.flat, bucket_mb << 20)]
+        self.reducers = [GradReducer(self.decoder_optimizer.flat, max(bucket_mb << 20, 4096))]
         broadcast_parameters(self.decoder_optimizer.flat)
         if self.encoder_optimizer is not None:
-            self.reducers.append(GradReducer(self.encoder_optimizer.flat, bucket_mb << 20))
+            self.reducers.append(GradReducer(self.encoder_optimizer.flat, max(bucket_mb << 20, 4096)))
             broadcast_parameters(self.encoder_optimizer.flat)
         self.decoder.train()
         self.encoder_call = self.encoder

@@ -461,23 +461,40 @@ def test_encoder_forward_backward_vs_cpu(dev):
 
 
 def test_shallow_trunk_gradients(dev):
-    """A 1-1-1-1 bottleneck stack (same block code as ResNet-152): GPU (MIOpen convs + fused BN kernels)
-    vs CPU fp64, outputs and every parameter gradient."""
-    from scnattn.resnet import resnet152_trunk
+    """A 1-1-1-1 bottleneck stack (same block code as ResNet-152) on the GPU: the fused BatchNorm kernels
+    against torch's own batch_norm/add/relu ops around the SAME MIOpen convolutions (tight), and against
+    CPU fp64 (loose: fp32 convolutions + ReLU-mask flips under batch statistics)."""
+    from scnattn.resnet import resnet152_trunk, FusedBatchNorm2d
     import copy
     torch.manual_seed(1)
     cpu = resnet152_trunk(depths=(1, 1, 1, 1)).double().train()
-    g = copy.deepcopy(cpu).float().to(dev).to(memory_format=torch.channels_last).train()
     x = torch.randn(8, 3, 96, 96)
     yc = cpu(x.double())
     w = torch.randn_like(yc)
     (yc * w).sum().backward()
     xg = x.to(dev).contiguous(memory_format=torch.channels_last)
-    y = g(xg)
-    _ok(y, yc, 1e-4, "trunk out")
-    (y * w.float().to(dev)).sum().backward()
-    for (k, p), (_, pc) in zip(g.named_parameters(), cpu.named_parameters()):
-        assert rel_err(p.grad, pc.grad) < 1e-2, (k, rel_err(p.grad, pc.grad))
+    res = {}
+    for fused in (True, False):
+        g = copy.deepcopy(cpu).float().to(dev).to(memory_format=torch.channels_last).train()
+        g.zero_grad()
+        FusedBatchNorm2d.use_fused = fused
+        try:
+            y = g(xg)
+            (y * w.float().to(dev)).sum().backward()
+        finally:
+            FusedBatchNorm2d.use_fused = True
+        res[fused] = (y.detach(), {k: p.grad.clone() for k, p in g.named_parameters()},
+                      {k: b.clone() for k, b in g.named_buffers()})
+    _ok(res[True][0], res[False][0], 2e-5, "fused vs torch BN: output")
+    for k in res[True][1]:
+        assert rel_err(res[True][1][k], res[False][1][k]) < 2e-2, (k, rel_err(res[True][1][k], res[False][1][k]))
+    for k in res[True][2]:
+        if not k.endswith("num_batches_tracked"):
+            assert rel_err(res[True][2][k], res[False][2][k]) < 1e-5, k
+    _ok(res[True][0], yc, 1e-4, "trunk out vs fp64")
+    worst_f = max(rel_err(res[True][1][k], p.grad) for k, p in cpu.named_parameters())
+    worst_t = max(rel_err(res[False][1][k], p.grad) for k, p in cpu.named_parameters())
+    assert worst_f < max(5e-2, 3 * worst_t), (worst_f, worst_t)   # no worse than torch's own fp32 path
 
 
 # ------------------------------------------------------------------------------------------------
@@ -569,3 +586,35 @@ def test_fused_optimizer_step_matches_reference_clip_adam(dev):
         oa.step()
         for (k, p), q in zip(a.named_parameters(), b.parameters()):
             _ok(p, q, 1e-5, k)
+
+
+def test_dp_reducer_on_rccl_single_rank(dev):
+    """The data-parallel code path on the real backend (nccl == RCCL) with a 1-rank group and the
+    reducers forced on: hooks fire during backward, buckets are gathered + all-reduced on the GPU, and
+    the parameters after one fused clamp+Adam step equal the non-distributed run's."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from trains.harness import TrainStep, synthetic_batch
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        kw = dict(kind="attention_scn", device=dev, encoder=False, batch_size=6, max_len=7, vocab_size=60,
+                  emb_dim=32, attention_dim=32, decoder_dim=32, factored_dim=32, semantic_dim=20, dropout=0.0,
+                  bucket_mb=0)
+        a = TrainStep(**kw)
+        b = TrainStep(**kw)
+        for r in b.reducers:
+            r.enabled = True     # world == 1 would normally bypass the collective
+        assert len(b.reducers[0].buckets) > 3
+        imgs, tags, caps, caplens = synthetic_batch(6, 60, 7, 8, 20, dev, 3, ragged=True)
+        enc = torch.rand(6, 14, 14, 2048, device=dev)
+        la = a.step(imgs, tags, caps, caplens, enc)
+        lb = b.step(imgs, tags, caps, caplens, enc)
+        torch.cuda.synchronize()
+        assert abs(la.item() - lb.item()) < 1e-6
+        assert all(b.reducers[0].launched)
+        assert torch.equal(a.decoder_optimizer.flat.flat_p, b.decoder_optimizer.flat.flat_p)
+    finally:
+        dist.destroy_process_group()
