@@ -381,40 +381,57 @@ def pool_permute(x, out_size):
 # fused BatchNorm2d (+ residual) (+ ReLU), channels-last  (csrc/batchnorm.hip)
 # ----------------------------------------------------------------------------------------------
 _bn_ws = {}
+_bn_fn = None
 
 
 def _bn_workspace(dev, C):
-    need = _lib.lib().scnattn_bn_workspace_floats(C)
     ws = _bn_ws.get(dev)
-    if ws is None or ws.numel() < need:
-        ws = torch.empty(max(need, 1 << 20), device=dev, dtype=torch.float32)
+    if ws is None or ws.numel() < 512 * C:
+        need = max(_lib.lib().scnattn_bn_workspace_floats(C), 1 << 20)
+        ws = torch.empty(need, device=dev, dtype=torch.float32)
         _bn_ws[dev] = ws    # stream-ordered reuse: every BN call on the device runs on the current stream
     return ws
+
+
+def _bn_fns():
+    """Pre-bound ctypes entry points: the BN group runs ~300 times per train step, so the Python cost per
+    call matters (the GPU kernels take 5-20 us each)."""
+    global _bn_fn
+    if _bn_fn is None:
+        h = _lib.lib()
+        _bn_fn = (h.scnattn_bn_stats, h.scnattn_bn_apply, h.scnattn_bn_bwd, torch._C._cuda_getCurrentRawStream)
+    return _bn_fn
 
 
 class _BNAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, res, gamma, beta, run_mean, run_var, training, momentum, eps, relu):
-        require_cuda(z, res, gamma, beta)
+        if not z.is_cuda:
+            raise RuntimeError("scnattn: fused BatchNorm needs tensors on an MI355X device; there is no CPU fallback")
         if z.dtype != torch.float32:
             z = z.float()
-        z = z.contiguous(memory_format=torch.channels_last)
-        if res is not None:
+        if not z.is_contiguous(memory_format=torch.channels_last):
+            z = z.contiguous(memory_format=torch.channels_last)
+        if res is not None and (res.dtype != torch.float32 or not res.is_contiguous(memory_format=torch.channels_last)):
             res = res.float().contiguous(memory_format=torch.channels_last)
         N, Cn, H, W = z.shape
         R = N * H * W
-        st = stream_of(z)
-        gamma, beta = f32c(gamma.detach()), f32c(beta.detach())
+        f_stats, f_apply, _, raw_stream = _bn_fns()
+        st = raw_stream(z.device.index)
         if training:
-            mean = torch.empty(Cn, device=z.device, dtype=torch.float32)
-            invstd = torch.empty(Cn, device=z.device, dtype=torch.float32)
-            call("scnattn_bn_stats", st, R, Cn, ptr(z), eps, momentum, ptr(_bn_workspace(z.device, Cn)), ptr(mean),
-                 ptr(invstd), ptr(run_mean), ptr(run_var))
+            stats = torch.empty((2, Cn), device=z.device, dtype=torch.float32)
+            mean, invstd = stats[0], stats[1]
+            rc = f_stats(st, R, Cn, z.data_ptr(), eps, momentum, _bn_workspace(z.device, Cn).data_ptr(),
+                         mean.data_ptr(), invstd.data_ptr(), run_mean.data_ptr(), run_var.data_ptr())
+            if rc:
+                _lib.check(rc, "scnattn_bn_stats")
         else:
             mean, invstd = run_mean.float(), torch.rsqrt(run_var.float() + eps)
-        y = torch.empty_like(z, memory_format=torch.channels_last)
-        call("scnattn_bn_apply", st, R, Cn, ptr(z), ptr(res), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
-             int(relu), ptr(y))
+        y = torch.empty_like(z)   # preserves the channels-last strides
+        rc = f_apply(st, R, Cn, z.data_ptr(), None if res is None else res.data_ptr(), mean.data_ptr(),
+                     invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), int(relu), y.data_ptr())
+        if rc:
+            _lib.check(rc, "scnattn_bn_apply")
         ctx.save_for_backward(z, y if relu else None, mean, invstd, gamma)
         ctx.cfg = (bool(training), bool(relu), res is not None)
         return y
@@ -425,15 +442,20 @@ class _BNAct(torch.autograd.Function):
         training, relu, has_res = ctx.cfg
         N, Cn, H, W = z.shape
         R = N * H * W
-        dy = dy.float().contiguous(memory_format=torch.channels_last)
+        if dy.dtype != torch.float32 or not dy.is_contiguous(memory_format=torch.channels_last):
+            dy = dy.float().contiguous(memory_format=torch.channels_last)
         need = ctx.needs_input_grad
-        dz = torch.empty_like(z, memory_format=torch.channels_last) if need[0] else None
-        dres = torch.empty_like(z, memory_format=torch.channels_last) if (has_res and need[1]) else None
-        dbeta = torch.empty(Cn, device=z.device, dtype=torch.float32)
-        dgamma = torch.empty(Cn, device=z.device, dtype=torch.float32)
-        call("scnattn_bn_bwd", stream_of(z), R, Cn, ptr(dy), ptr(y), ptr(z), ptr(mean), ptr(invstd), ptr(gamma),
-             int(relu), int(training), ptr(_bn_workspace(z.device, Cn)), ptr(dbeta), ptr(dgamma), ptr(dz), ptr(dres))
-        return (dz, dres, dgamma if need[2] else None, dbeta if need[3] else None, None, None, None, None, None, None)
+        dz = torch.empty_like(z) if need[0] else None
+        dres = torch.empty_like(z) if (has_res and need[1]) else None
+        dgb = torch.empty((2, Cn), device=z.device, dtype=torch.float32)
+        _, _, f_bwd, raw_stream = _bn_fns()
+        rc = f_bwd(raw_stream(z.device.index), R, Cn, dy.data_ptr(), None if y is None else y.data_ptr(), z.data_ptr(),
+                   mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), int(relu), int(training),
+                   _bn_workspace(z.device, Cn).data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
+                   None if dz is None else dz.data_ptr(), None if dres is None else dres.data_ptr())
+        if rc:
+            _lib.check(rc, "scnattn_bn_bwd")
+        return (dz, dres, dgb[1] if need[2] else None, dgb[0] if need[3] else None, None, None, None, None, None, None)
 
 
 def bn_act(z, res, gamma, beta, run_mean, run_var, training, momentum, eps, relu):

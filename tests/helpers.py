@@ -30,3 +30,11 @@ def rel_err(a, b):
     b = torch.as_tensor(b, dtype=torch.float64).cpu()
     denom = max(b.abs().max().item(), 1e-30)
     return (a - b).abs().max().item() / denom
+
+
+def rel_l2(a, b):
+    """||a-b||_2 / ||b||_2: robust to the handful of ReLU-mask flips that dominate a max-norm comparison of
+    gradients of deep batch-normalised conv stacks."""
+    a = torch.as_tensor(a, dtype=torch.float64).cpu()
+    b = torch.as_tensor(b, dtype=torch.float64).cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()

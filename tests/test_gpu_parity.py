@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import load_golden, params_from, t, rel_err
+from helpers import load_golden, params_from, t, rel_err, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -487,14 +487,14 @@ def test_shallow_trunk_gradients(dev):
                       {k: b.clone() for k, b in g.named_buffers()})
     _ok(res[True][0], res[False][0], 2e-5, "fused vs torch BN: output")
     for k in res[True][1]:
-        assert rel_err(res[True][1][k], res[False][1][k]) < 2e-2, (k, rel_err(res[True][1][k], res[False][1][k]))
+        assert rel_l2(res[True][1][k], res[False][1][k]) < 5e-3, (k, rel_l2(res[True][1][k], res[False][1][k]))
     for k in res[True][2]:
         if not k.endswith("num_batches_tracked"):
             assert rel_err(res[True][2][k], res[False][2][k]) < 1e-5, k
     _ok(res[True][0], yc, 1e-4, "trunk out vs fp64")
-    worst_f = max(rel_err(res[True][1][k], p.grad) for k, p in cpu.named_parameters())
-    worst_t = max(rel_err(res[False][1][k], p.grad) for k, p in cpu.named_parameters())
-    assert worst_f < max(5e-2, 3 * worst_t), (worst_f, worst_t)   # no worse than torch's own fp32 path
+    worst_f = max(rel_l2(res[True][1][k], p.grad) for k, p in cpu.named_parameters())
+    worst_t = max(rel_l2(res[False][1][k], p.grad) for k, p in cpu.named_parameters())
+    assert worst_f < max(1e-2, 3 * worst_t), (worst_f, worst_t)   # no worse than torch's own fp32 path
 
 
 # ------------------------------------------------------------------------------------------------
