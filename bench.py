@@ -89,6 +89,23 @@ def cpu_baseline(kind, cfg, fine_tune, budget_s=30.0):
                                                           cfg["max_len"] + 1, cfg["vocab_size"], Bc, dt, ncores)}
 
 
+def warm_miopen(dev, batch, fine_tune):
+    """One throw-away ResNet-152 forward/backward so that MIOpen's compiled kernels are in the on-disk
+    cache before the other ranks start."""
+    from models.encoders.caption import EncoderCaption
+    torch.backends.cudnn.benchmark = True
+    enc = EncoderCaption(channels_last=True).to(dev)
+    enc.fine_tune(fine_tune)
+    enc.train()
+    x = torch.randn(batch, 3, 256, 256, device=dev)
+    y = enc(x)
+    if fine_tune:
+        y.sum().backward()
+    torch.cuda.synchronize()
+    del enc, x, y
+    torch.cuda.empty_cache()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,6 +120,8 @@ def main():
     ap.add_argument("--ksplit", type=int, default=0)
     ap.add_argument("--with-tagger", action="store_true",
                     help="also run the frozen EncoderTagger ResNet-152 each step (the reference's real step)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="diagnostics: run the multi-rank code path (RCCL group, barriers, reducers) with one rank")
     ap.add_argument("--forward-only", action="store_true", help="diagnostics: decoder forward only (PMC passes)")
     ap.add_argument("--graph", action="store_true", help="replay the encoder as HIP graphs (measured slower)")
     args = ap.parse_args()
@@ -113,7 +132,13 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the product path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
@@ -123,8 +148,15 @@ def main():
     if args.ksplit:
         SF.set_option("ksplit", args.ksplit)
     fine_tune = not args.no_finetune
+    # MIOpen JIT-compiles its convolution kernels on first use (this image has no gfx950 kernel database)
+    # and caches the binaries per user.  With N ranks starting together every rank would compile the same
+    # ~150 kernels at once on shared host cores: let rank 0 populate the cache first.
+    if dist_on:
+        if rank == 0 and not args.decoder_only:
+            warm_miopen(dev, args.batch, fine_tune)      # no collective inside
+        dist.barrier()                                    # first collective on every rank
     ts = TrainStep(kind=args.workload, fine_tune_encoder=fine_tune, device=dev, encoder=not args.decoder_only,
-                   batch_size=args.batch, max_len=args.max_len, graph_encoder=args.graph, tagger=args.with_tagger)
+                   batch_size=args.batch, max_len=args.max_len, graph_encoder=args.graph, tagger=args.with_tagger, force_reduce=args.force_dist)
     cfg = ts.cfg
     imgs, tags, caps, caplens = synthetic_batch(args.batch, cfg["vocab_size"], cfg["max_len"], cfg["image_size"],
                                                 cfg["semantic_dim"], dev, 1234 + rank)
@@ -145,19 +177,19 @@ def main():
     prof = (ctypes.c_double * 4)()
     torch.cuda.synchronize()
     _lib.call("scnattn_profile_collect", prof)   # drop warm-up events
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(args.steps)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     _lib.call("scnattn_profile_collect", prof)
     SF.set_option("profile", 0)
-    if world > 1:
+    if dist_on:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -206,7 +238,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

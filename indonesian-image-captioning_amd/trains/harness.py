@@ -58,7 +58,7 @@ def build_decoder(kind, cfg):
 
 class TrainStep:
     def __init__(self, kind="attention_scn", fine_tune_encoder=True, device="cuda", seed=1234, encoder=True,
-                 bucket_mb=32, graph_encoder=False, tagger=False, **overrides):
+                 bucket_mb=32, graph_encoder=False, tagger=False, force_reduce=False, **overrides):
         self.cfg = dict(DEFAULTS)
         self.cfg.update(overrides)
         self.kind = kind
@@ -93,6 +93,9 @@ class TrainStep:
         if self.encoder_optimizer is not None:
             self.reducers.append(GradReducer(self.encoder_optimizer.flat, max(bucket_mb << 20, 4096)))
             broadcast_parameters(self.encoder_optimizer.flat)
+        if force_reduce:          # diagnostics: exercise hooks + collectives with a single rank
+            for r in self.reducers:
+                r.enabled = True
         self.decoder.train()
         self.encoder_call = self.encoder
         if self.encoder is not None:
