@@ -108,6 +108,19 @@ __global__ __launch_bounds__(512) void attn_context_kernel(int rows, int P, int 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, e0 = blockIdx.x * 256;
 
+    // The first batch of encoder rows does not depend on the softmax: put it in flight before the
+    // (barrier-heavy) softmax prologue.  CU = 8 rows per wave per batch -> 8 x 16 B loads in flight per lane.
+    constexpr int CU = 8;
+    const int col = e0 + lane * 4;
+    const float* base = enc + (long)b * P * E;
+    const int cc = min(col, max(E - 4, 0));
+    const bool cok = col < E;
+    f32x4 v[CU];
+    if (VEC) {
+#pragma unroll
+        for (int j = 0; j < CU; ++j) v[j] = *reinterpret_cast<const f32x4*>(base + (long)min(wave + 8 * j, P - 1) * E + cc);
+    }
+
     if (MODE == 0) {
         float m = -INFINITY;
         for (int p = tid; p < P; p += 512) m = fmaxf(m, e[(long)b * P + p]);
@@ -130,25 +143,24 @@ __global__ __launch_bounds__(512) void attn_context_kernel(int rows, int P, int 
         __syncthreads();
     }
 
-    const int col = e0 + lane * 4;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    const float* base = enc + (long)b * P * E;
     if (VEC) {
-        const int cc = min(col, E - 4);
-        const bool cok = col < E;
-        for (int p = wave; p < P; p += 32) {
-            f32x4 v[4];
-            float al[4];
+        for (int p = wave;;) {
+            float al[CU];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < CU; ++j) {
                 const int pp = p + 8 * j;
-                v[j] = *reinterpret_cast<const f32x4*>(base + (long)min(pp, P - 1) * E + cc);
                 al[j] = (pp < P && cok) ? (MODE == 0 ? alph[min(pp, P - 1)] : 1.f) : 0.f;
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < CU; ++j)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[c] = fmaf(al[j], v[j][c], acc[c]);
+            p += 8 * CU;
+            if (p >= P) break;
+#pragma unroll
+            for (int j = 0; j < CU; ++j)
+                v[j] = *reinterpret_cast<const f32x4*>(base + (long)min(p + 8 * j, P - 1) * E + cc);
         }
     } else {
         for (int p = wave; p < P; p += 8) {
@@ -194,8 +206,6 @@ __global__ __launch_bounds__(256) void attn_dalpha_kernel(int rows, int P, int E
     const int E4 = (E + 3) & ~3;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, p0 = blockIdx.x * PC;
-    for (int c = tid; c < E4; c += 256) sm[c] = c < E ? dawe[(long)b * E + c] : 0.f;
-    __syncthreads();
     const float* rowp[4];
     bool ok[4];
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -206,17 +216,38 @@ __global__ __launch_bounds__(256) void attn_dalpha_kernel(int rows, int P, int E
         rowp[j] = enc + ((long)b * P + (ok[j] ? p : P - 1)) * E;
     }
     if (VEC) {
-        for (int c = lane * 4; c < E; c += 256) {
-            const f32x4 d = *reinterpret_cast<const f32x4*>(sm + c);
-            f32x4 v[4];
+        // 2 column chunks x 4 rows = 8 x 16 B loads in flight per lane; the first batch is issued before
+        // the LDS staging of dawe (it does not depend on it)
+        f32x4 v[2][4];
+        const int cmax = E - 4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4*>(rowp[j] + c);
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j) v[u][j] = *reinterpret_cast<const f32x4*>(rowp[j] + min(lane * 4 + 256 * u, cmax));
+        for (int c = tid; c < E4; c += 256) sm[c] = c < E ? dawe[(long)b * E + c] : 0.f;
+        __syncthreads();
+        for (int c0 = lane * 4;;) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) acc[j] = fmaf(v[j][k], d[k], acc[j]);
+            for (int u = 0; u < 2; ++u) {
+                const int c = c0 + 256 * u;
+                if (c < E) {
+                    const f32x4 d = *reinterpret_cast<const f32x4*>(sm + c);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc[j] = fmaf(v[u][j][k], d[k], acc[j]);
+                }
+            }
+            c0 += 512;
+            if (c0 >= E) break;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[u][j] = *reinterpret_cast<const f32x4*>(rowp[j] + min(c0 + 256 * u, cmax));
         }
     } else {
+        for (int c = tid; c < E4; c += 256) sm[c] = c < E ? dawe[(long)b * E + c] : 0.f;
+        __syncthreads();
         for (int c = lane; c < E; c += 64) {
             const float d = sm[c];
 #pragma unroll
