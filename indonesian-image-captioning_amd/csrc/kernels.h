@@ -73,7 +73,7 @@ int colsum(hipStream_t st, int R, int N, const float* X, long ld, float* out, fl
 int gather_rows_tm(hipStream_t st, int B, int T, int L, int M, const long long* caps, const float* table,
                    int V, float* out_tm);
 int scatter_add_rows_tm(hipStream_t st, int B, int T, int L, int M, const long long* caps, const int* dl,
-                        const float* demb_tm, int V, float* dtable);
+                        const float* demb_tm, int V, float* dtable, int* present);
 int hidden_to_bm(hipStream_t st, int B, int T, int D, const int* dl, const float* hs_tm,
                  const float* mask_bm, float* out_bm, float* rowmask);
 int hidden_from_bm(hipStream_t st, int B, int T, int D, const int* dl, const float* dbm,

@@ -76,21 +76,69 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(int B, int T, int L, i
     for (int m = threadIdx.x; m < M; m += 256) dst[m] = src[m];
 }
 
-// dtable[caps[b][t]][:] += demb_tm[t][b][:] for active (t < dl[b]) cells.  One workgroup per
-// (token-owning) cell; duplicates are resolved with float atomics (order-dependent in the last bit).
+// dtable[v][:] += sum over active cells (t < dl[b]) with caps[b][t] == v of demb_tm[t][b][:].
+// One workgroup per vocabulary row scans the (small) token list in a fixed order, so the result is
+// bitwise reproducible -- no float atomics (the reference's nn.Embedding backward is deterministic too).
+__global__ __launch_bounds__(256) void mark_tokens_kernel(int B, int T, int L, const long long* __restrict__ caps,
+                                                          const int* __restrict__ dl, int V, int* __restrict__ present) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= T * B) return;
+    const int t = r / B, b = r - t * B;
+    const long long tok = caps[(long)b * L + t];
+    if (t < dl[b] && tok >= 0 && tok < V) present[tok] = 1;   // benign race: every writer stores 1
+}
+
 __global__ __launch_bounds__(256) void scatter_add_rows_kernel(int B, int T, int L, int M,
                                                                const long long* __restrict__ caps,
                                                                const int* __restrict__ dl,
                                                                const float* __restrict__ demb, int V,
+                                                               const int* __restrict__ present,
                                                                float* __restrict__ dtable) {
-    const int row = blockIdx.x;
-    const int t = row / B, b = row - t * B;
-    if (t >= dl[b]) return;
-    long long tok = caps[(long)b * L + t];
-    if (tok < 0 || tok >= V) return;
-    const float* src = demb + (long)row * M;
-    float* dst = dtable + tok * M;
-    for (int m = threadIdx.x; m < M; m += 256) atomicAdd(dst + m, src[m]);
+    constexpr int MAXH = 1024;
+    __shared__ int list[MAXH];
+    __shared__ int nlist;
+    const int v = blockIdx.x;
+    const int TB = T * B;
+    if (!present[v]) return;      // most vocabulary rows do not occur in the batch
+    if (threadIdx.x == 0) nlist = 0;
+    __syncthreads();
+    // collect the cells that hold token v (append order is arbitrary) ...
+    for (int r = threadIdx.x; r < TB; r += 256) {
+        const int t = r / B, b = r - t * B;
+        if (t < dl[b] && caps[(long)b * L + t] == v) {
+            const int i = atomicAdd(&nlist, 1);
+            if (i < MAXH) list[i] = r;
+        }
+    }
+    __syncthreads();
+    const int n = nlist;
+    if (n > MAXH) {
+        // a token filling more than MAXH cells (degenerate data): plain ordered scan, still deterministic
+        for (int m = threadIdx.x; m < M; m += 256) {
+            float acc = 0.f;
+            for (int r = 0; r < TB; ++r) {
+                const int t = r / B, b = r - t * B;
+                if (t < dl[b] && caps[(long)b * L + t] == v) acc += demb[(long)r * M + m];
+            }
+            dtable[(long)v * M + m] += acc;
+        }
+        return;
+    }
+    // ... then sort them so that the summation order is fixed (bitwise reproducible result)
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < n; ++i) {
+            const int key = list[i];
+            int j = i - 1;
+            while (j >= 0 && list[j] > key) { list[j + 1] = list[j]; --j; }
+            list[j + 1] = key;
+        }
+    }
+    __syncthreads();
+    for (int m = threadIdx.x; m < M; m += 256) {
+        float acc = 0.f;
+        for (int i = 0; i < n; ++i) acc += demb[(long)list[i] * M + m];
+        dtable[(long)v * M + m] += acc;
+    }
 }
 
 // out_bm[b][t][:] = (t < dl[b]) ? hs_tm[t][b][:] * mask[b][t][:] : 0 ; rowmask[b*T+t] = t < dl[b]
@@ -265,10 +313,14 @@ int gather_rows_tm(hipStream_t st, int B, int T, int L, int M, const long long* 
 }
 
 int scatter_add_rows_tm(hipStream_t st, int B, int T, int L, int M, const long long* caps, const int* dl,
-                        const float* demb_tm, int V, float* dtable) {
+                        const float* demb_tm, int V, float* dtable, int* present) {
     if (B <= 0 || T <= 0) return 0;
-    SCN_ARG(caps && dl && demb_tm && dtable && T <= L, "scatter_add_rows_tm: bad argument");
-    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(B * T), dim3(256), 0, st, B, T, L, M, caps, dl, demb_tm, V, dtable);
+    SCN_ARG(caps && dl && demb_tm && dtable && present && T <= L, "scatter_add_rows_tm: bad argument");
+    SCN_HIP(hipMemsetAsync(present, 0, sizeof(int) * V, st));
+    hipLaunchKernelGGL(mark_tokens_kernel, dim3(cdiv((long)T * B, 256)), dim3(256), 0, st, B, T, L, caps, dl, V, present);
+    SCN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(V), dim3(256), 0, st, B, T, L, M, caps, dl, demb_tm, V, present,
+                       dtable);
     SCN_LAUNCH_CHECK();
     return 0;
 }

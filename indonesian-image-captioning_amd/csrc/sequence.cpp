@@ -89,7 +89,7 @@ struct FwdScratch {
 
 struct BwdScratch {
     float *WDb, *WaTz, *WcatT, *dHd_bm, *dhfc_tm, *dr_all, *dpx_all, *dcat_all, *dawe_all, *de_all, *dalpha, *dc,
-        *dqx_acc, *dqh_acc, *sDb, *sZ, *sH, *datt1, *dwpart, *dwtmp, *demb_tm, *dmean, *dh0, *mx_all, *gws;
+        *dqx_acc, *dqh_acc, *sDb, *sZ, *sH, *datt1, *dwpart, *dwtmp, *demb_tm, *dmean, *dh0, *mx_all, *gws, *present;
 };
 
 inline size_t sz(long a, long b = 1, long c = 1, long d = 1) { return (size_t)a * b * c * d; }
@@ -162,6 +162,7 @@ size_t carve_bwd(const scnattn_dims& d, float* base, BwdScratch& s) {
     s.dmean = c.take(sz(B, E));
     s.dh0 = c.take(sz(B, D));
     s.mx_all = c.take(sz(T, B, F4));
+    s.present = c.take(sz(d.V));
     s.gws = c.take(GEMM_WS_FLOATS);
     return c.off * sizeof(float);
 }
@@ -388,7 +389,7 @@ int seq_bwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
         SCN_TRY(sgemm_ws(st, false, true, TB, M, F4, 1.f, k.dpx_all, F4, w->decode_step_weight_ia, F4, 0.f, k.demb_tm, M,
                       nullptr, nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
         SCN_TRY(scatter_add_rows_tm(st, B, T, d.L, M, (const long long*)caps, dl_dev, k.demb_tm, V,
-                                    g->embedding_weight));
+                                    g->embedding_weight, reinterpret_cast<int*>(k.present)));
     }
     if (g->decode_step_weight_ic) {
         SCN_TRY(mul_bcast(st, T, B, F4, s.pa_all, s.qx, k.mx_all));

@@ -615,6 +615,36 @@ def test_dp_reducer_on_rccl_single_rank(dev):
         torch.cuda.synchronize()
         assert abs(la.item() - lb.item()) < 1e-6
         assert all(b.reducers[0].launched)
-        assert torch.equal(a.decoder_optimizer.flat.flat_p, b.decoder_optimizer.flat.flat_p)
+        assert torch.equal(a.decoder_optimizer.flat.flat_p, b.decoder_optimizer.flat.flat_p)   # bitwise: no atomics anywhere
     finally:
         dist.destroy_process_group()
+
+
+def test_embedding_gradient_is_deterministic_and_handles_repeated_tokens(dev):
+    """All captions use the same few tokens (every vocabulary row that occurs is hit by hundreds of
+    cells, one of them more than the kernel's in-LDS list holds): the embedding gradient must equal the
+    oracle's and be bitwise identical across runs (no float atomics)."""
+    from oracle import scnattn_ref as R
+    from models.decoders.pure_scn import PureSCN
+    torch.manual_seed(0)
+    B, V, L = 48, 12, 40
+    m = PureSCN(16, 16, 16, 6, V, encoder_dim=24, dropout=0.0)
+    enc = torch.rand(B, 2, 2, 24)
+    tags = torch.rand(B, 6)
+    caps = torch.randint(1, 4, (B, L))
+    caps[:, ::2] = 5                     # token 5 fills > 1024 of the 48*39 cells
+    caplens = torch.full((B, 1), L)
+    P = {k: v.detach().clone().double().requires_grad_(True) for k, v in m.state_dict().items()}
+    pr, cs, dl, _ = R.pure_scn_forward(P, enc.double(), tags.double(), caps, caplens)
+    loss_r, _, _ = R.caption_loss(pr, cs, dl, None)
+    loss_r.backward()
+    m = m.to(dev).train()
+    grads = []
+    for _ in range(2):
+        m.zero_grad()
+        preds, caps_s, dl2, _ = m(enc.to(dev), tags.to(dev), caps.to(dev), caplens.to(dev))
+        loss, _, _ = R.caption_loss(preds, caps_s, dl2, None)
+        loss.backward()
+        grads.append(m.embedding.weight.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    _ok(grads[0], P["embedding.weight"].grad, TOL_GRAD, "embedding grad")
