@@ -634,15 +634,16 @@ def test_embedding_gradient_is_deterministic_and_handles_repeated_tokens(dev):
     caps = torch.randint(1, 4, (B, L))
     caps[:, ::2] = 5                     # token 5 fills > 1024 of the 48*39 cells
     caplens = torch.full((B, 1), L)
+    si = torch.arange(B)     # all lengths tie: pin the permutation (quirk Q2: the sort is not stable on CPU)
     P = {k: v.detach().clone().double().requires_grad_(True) for k, v in m.state_dict().items()}
-    pr, cs, dl, _ = R.pure_scn_forward(P, enc.double(), tags.double(), caps, caplens)
+    pr, cs, dl, _ = R.pure_scn_forward(P, enc.double(), tags.double(), caps, caplens, sort_ind=si)
     loss_r, _, _ = R.caption_loss(pr, cs, dl, None)
     loss_r.backward()
     m = m.to(dev).train()
     grads = []
     for _ in range(2):
         m.zero_grad()
-        preds, caps_s, dl2, _ = m(enc.to(dev), tags.to(dev), caps.to(dev), caplens.to(dev))
+        preds, caps_s, dl2, _ = m(enc.to(dev), tags.to(dev), caps.to(dev), caplens.to(dev), sort_ind=si.to(dev))
         loss, _, _ = R.caption_loss(preds, caps_s, dl2, None)
         loss.backward()
         grads.append(m.embedding.weight.grad.clone())
