@@ -143,3 +143,37 @@ class TrainStep:
         if self.encoder_optimizer is not None:
             self.encoder_optimizer.step(scale)
         return loss
+
+
+def validate(batches, encoder, encoder_tagger, decoder, criterion, word_map, alpha_c=1.0):
+    """The reference's validate() (trains/attention_scn.py:274-385): eval-mode forward under no_grad,
+    loss / top-5 accuracy bookkeeping, references and arg-max hypotheses, corpus BLEU-4.
+    `batches` yields (imgs, caps, caplens, allcaps) already on the device; `encoder_tagger` may be a
+    callable returning tags or None when the batch tuple carries tags in place of images for it."""
+    from utils.metric import AverageMeter, accuracy, corpus_bleu
+    decoder.eval()
+    encoder.eval()
+    if hasattr(encoder_tagger, "eval"):
+        encoder_tagger.eval()
+    losses, top5accs = AverageMeter(), AverageMeter()
+    references, hypotheses = [], []
+    skip = {word_map['<start>'], word_map['<pad>']}
+    with torch.no_grad():
+        for imgs, caps, caplens, allcaps in batches:
+            encoder_out = encoder(imgs)
+            tags = encoder_tagger(imgs)
+            scores, caps_sorted, decode_lengths, alphas, sort_ind = decoder(encoder_out, tags, caps, caplens)
+            targets = caps_sorted[:, 1:]
+            scores_copy = scores.clone()
+            scores_p = pack_padded_sequence(scores, decode_lengths, batch_first=True).data
+            targets_p = pack_padded_sequence(targets, decode_lengths, batch_first=True).data
+            loss = criterion(scores_p, targets_p) + alpha_c * ((1. - alphas.sum(dim=1)) ** 2).mean()
+            losses.update(loss.item(), sum(decode_lengths))
+            top5accs.update(accuracy(scores_p, targets_p, 5), sum(decode_lengths))
+            allcaps = allcaps[sort_ind]
+            for j in range(allcaps.shape[0]):
+                references.append([[w for w in c if w not in skip] for c in allcaps[j].tolist()])
+            preds = torch.max(scores_copy, dim=2)[1].tolist()
+            hypotheses.extend(p[:decode_lengths[j]] for j, p in enumerate(preds))
+    assert len(references) == len(hypotheses)
+    return corpus_bleu(references, hypotheses), losses.avg, top5accs.avg

@@ -649,3 +649,40 @@ def test_embedding_gradient_is_deterministic_and_handles_repeated_tokens(dev):
         grads.append(m.embedding.weight.grad.clone())
     assert torch.equal(grads[0], grads[1])
     _ok(grads[0], P["embedding.weight"].grad, TOL_GRAD, "embedding grad")
+
+
+def test_validate_path(dev):
+    """validate() (trains/attention_scn.py:274-385) on the HIP decoder vs the same bookkeeping done with
+    the CPU oracle: loss, top-5 accuracy and corpus BLEU-4 (NLTK-free)."""
+    from oracle import scnattn_ref as R
+    from models.decoders.attention_scn import AttentionSCN
+    from trains.harness import validate
+    from utils.metric import corpus_bleu
+    torch.manual_seed(3)
+    B, V, L = 6, 40, 9
+    wm = {"<pad>": 0, "<unk>": V - 3, "<start>": V - 2, "<end>": V - 1}
+    m = AttentionSCN(24, 20, 28, 36, 14, V, encoder_dim=40, dropout=0.5)
+    g = torch.Generator().manual_seed(5)
+    enc = torch.rand(B, 3, 3, 40, generator=g)
+    tags = torch.rand(B, 14, generator=g)
+    lens = torch.tensor([9, 7, 8, 5, 6, 4])
+    caps = torch.zeros(B, L, dtype=torch.long)
+    for b in range(B):
+        n = int(lens[b]); caps[b, 0] = V - 2; caps[b, 1:n - 1] = torch.randint(1, V - 3, (n - 2,), generator=g); caps[b, n - 1] = V - 1
+    allcaps = torch.stack([caps, caps.roll(1, 0)], dim=1)           # 2 references per image
+    caplens = lens.unsqueeze(1)
+    P = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    pr, cs, dl, al, si = R.attention_scn_forward(P, enc, tags, caps, caplens)
+    loss_r, sc, tg = R.caption_loss(pr, cs, dl, al, 1.0)
+    skip = {wm["<start>"], wm["<pad>"]}
+    refs = [[[w for w in c if w not in skip] for c in allcaps[si][j].tolist()] for j in range(B)]
+    hyps = [p[:dl[j]] for j, p in enumerate(pr.argmax(dim=2).tolist())]
+    bleu_r = corpus_bleu(refs, hyps)
+    m = m.to(dev)
+    crit = torch.nn.CrossEntropyLoss()
+    bleu, loss, top5 = validate([(None, caps.to(dev), caplens.to(dev), allcaps.to(dev))], type("E", (), {"eval": lambda s: None, "__call__": lambda s, x: enc.to(dev)})(),
+                                lambda x: tags.to(dev), m, crit, wm)
+    assert not m.training
+    assert abs(loss - loss_r.item()) < 1e-4 * abs(loss_r.item())
+    assert abs(top5 - R.topk_accuracy(sc, tg, 5)) < 1e-6
+    assert abs(bleu - bleu_r) < 1e-12

@@ -205,3 +205,26 @@ def test_encoder_trunk_matches_independent_resnet_definition():
         y, yh = ours(x), hf(x).last_hidden_state
     assert y.shape == yh.shape == (2, 2048, 3, 3)
     assert (y - yh).abs().max().item() <= 1e-4 * yh.abs().max().item()
+
+
+def test_corpus_bleu_known_values():
+    """NLTK-free corpus BLEU (utils/metric.py) against hand-computed values of the standard definition."""
+    import math
+    from utils.metric import corpus_bleu, AverageMeter
+    ref = [[1, 2, 3, 4, 5, 6, 7, 8]]
+    assert abs(corpus_bleu([ref], [[1, 2, 3, 4, 5, 6, 7, 8]]) - 1.0) < 1e-12
+    # hypothesis = first 6 tokens: all n-gram precisions 1, brevity penalty exp(1 - 8/6)
+    assert abs(corpus_bleu([ref], [[1, 2, 3, 4, 5, 6]]) - math.exp(1 - 8 / 6)) < 1e-12
+    # one substitution in the middle: p1 = 7/8, p2 = 5/7, p3 = 3/6, p4 = 1/5, BP = 1
+    want = math.exp(0.25 * (math.log(7 / 8) + math.log(5 / 7) + math.log(3 / 6) + math.log(1 / 5)))
+    assert abs(corpus_bleu([ref], [[1, 2, 3, 9, 5, 6, 7, 8]]) - want) < 1e-12
+    # clipping + closest reference length + corpus-level pooling over two segments
+    refs = [[[1, 1, 2, 3], [1, 2, 3, 4, 5]], [[7, 8, 9, 10]]]
+    hyps = [[1, 1, 1, 2, 3], [7, 8, 9, 10]]
+    # n=1: seg1 clipped 1x2 + 2 + 3 -> 4 of 5, seg2 4 of 4 -> 8/9 ; n=2: (1,1)x1,(1,2),(2,3) -> 3 of 4, 3 of 3 -> 6/7
+    # n=3: (1,1,2),(1,2,3) -> 2 of 3, 2 of 2 -> 4/5 ; n=4: (1,1,2,3) -> 1 of 2, 1 of 1 -> 2/3 ; len 9 vs ref 5+4 -> BP 1
+    want = math.exp(0.25 * (math.log(8 / 9) + math.log(6 / 7) + math.log(4 / 5) + math.log(2 / 3)))
+    assert abs(corpus_bleu(refs, hyps) - want) < 1e-12
+    assert corpus_bleu([ref], [[9, 9, 9, 9]]) == 0.0
+    m = AverageMeter(); m.update(2.0, 3); m.update(4.0, 1)
+    assert m.val == 4.0 and m.count == 4 and abs(m.avg - 2.5) < 1e-12
