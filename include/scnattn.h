@@ -28,11 +28,12 @@ extern "C" {
 int scnattn_version(void);
 const char* scnattn_last_error(void);
 /* Options: "ksplit" (force the split-K factor of the skinny GEMMs; 0 = auto), "profile" (1: bracket
- * the recurrence loops with HIP events on the caller's stream).  Returns -1 for an unknown name. */
+ * the recurrence loops with HIP events on the caller's stream; 2: also every attn_context launch).
+ * Returns -1 for an unknown name. */
 int scnattn_set_option(const char* name, int value);
-/* Sum of the event-timed recurrence loops since the last call:
- * out4 = {forward loop ms, forward steps, backward loop ms, backward steps}.  Synchronises on the events. */
-int scnattn_profile_collect(double* out4);
+/* Sums since the last call: out6 = {forward loop ms, forward steps, backward loop ms, backward steps,
+ * attn_context ms, attn_context launches}.  Synchronises on the recorded events. */
+int scnattn_profile_collect(double* out6);
 
 /* ---- dimensions of one decoder (models/decoders/attention_scn.py:28-56, pure_scn.py:26-48) ------ */
 typedef struct {

@@ -54,9 +54,9 @@ int scnattn_set_option(const char* name, int value) {
     return -1;
 }
 
-int scnattn_profile_collect(double* out4) {
-    if (!out4) { set_error("scnattn_profile_collect: NULL"); return -1; }
-    return profile_collect(out4);
+int scnattn_profile_collect(double* out6) {
+    if (!out6) { set_error("scnattn_profile_collect: NULL"); return -1; }
+    return profile_collect(out6);
 }
 
 int scnattn_seq_workspace(const scnattn_dims* d, size_t* saved_bytes, size_t* scratch_bytes) {

@@ -43,14 +43,15 @@ static void prof_end(hipStream_t st, hipEvent_t a, int kind, int steps) {
     g_prof.push_back(LoopEvent{a, b, kind, steps});
 }
 
-// out[0..3] = {fwd loop ms, fwd steps, bwd loop ms, bwd steps} summed since the last collect
+// out[0..5] = {fwd loop ms, fwd steps, bwd loop ms, bwd steps, attn_context ms, attn_context launches}
+// summed since the last collect (the last pair only when option "profile" was 2)
 int profile_collect(double* out) {
     std::vector<LoopEvent> ev;
     {
         std::lock_guard<std::mutex> lk(g_prof_mu);
         ev.swap(g_prof);
     }
-    out[0] = out[1] = out[2] = out[3] = 0.0;
+    for (int i = 0; i < 6; ++i) out[i] = 0.0;
     for (auto& e : ev) {
         float ms = 0.f;
         SCN_HIP(hipEventSynchronize(e.b));
@@ -270,9 +271,11 @@ int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
             SCN_TRY(attn_scores(st, bt_, P, A, s.att1, Slabs{f.slabA, ksA, (long)B * NA, NA},
                                 w->attention_decoder_att_bias, w->attention_full_att_weight,
                                 w->attention_full_att_bias, f.e, s.att2_all + (long)t * B * A));
+            hipEvent_t evc = g_profile >= 2 ? prof_begin(st) : nullptr;   // per-launch timing of the dominant kernel
             SCN_TRY(attn_context(st, bt_, P, E, enc, f.e, Slabs{f.slabA + A, ksA, (long)B * NA, NA}, w->f_beta_bias,
                                  alphas + (long)t * P, (long)T * P, s.alpha_tm + (long)t * B * P,
                                  s.awe_all + (long)t * B * E, s.gate_all + (long)t * B * E, s.z_all + (long)t * B * E));
+            prof_end(st, evc, 2, 1);
             const int ksC = pick(bt_, F4, E, 1);
             SCN_TRY(skinny_gemm(st, bt_, F4, E, 1, s.z_all + (long)t * B * E, E, 0,
                                 w->decode_step_weight_ia + (long)M * F4, F4, 0, f.slabC, F4, 0, (long)B * F4, ksC));
