@@ -686,3 +686,71 @@ def test_validate_path(dev):
     assert abs(loss - loss_r.item()) < 1e-4 * abs(loss_r.item())
     assert abs(top5 - R.topk_accuracy(sc, tg, 5)) < 1e-6
     assert abs(bleu - bleu_r) < 1e-12
+
+
+def test_tags_gradient_and_eval_mode(dev):
+    """d loss / d semantic_input (only formed when the tags require grad, e.g. a trainable tagger head) and
+    eval()-mode forward (dropout off even with p = 0.5)."""
+    from oracle import scnattn_ref as R
+    from models.decoders.attention_scn import AttentionSCN
+    torch.manual_seed(9)
+    B, V, L = 5, 30, 8
+    m = AttentionSCN(24, 20, 28, 36, 14, V, encoder_dim=40, dropout=0.5)
+    g = torch.Generator().manual_seed(2)
+    enc = torch.rand(B, 3, 3, 40, generator=g)
+    tags = torch.rand(B, 14, generator=g)
+    lens = torch.tensor([8, 6, 7, 3, 5])
+    caps = torch.randint(1, V - 3, (B, L), generator=g)
+    caplens = lens.unsqueeze(1)
+    P = {k: v.detach().clone().double() for k, v in m.state_dict().items()}
+    t1 = tags.double().requires_grad_(True)
+    pr, cs, dl, al, si = R.attention_scn_forward(P, enc.double(), t1, caps, caplens)
+    loss_r, _, _ = R.caption_loss(pr, cs, dl, al, 1.0)
+    loss_r.backward()
+    m = m.to(dev).eval()
+    t2 = tags.to(dev).requires_grad_(True)
+    preds, caps_s, dl2, alphas, _ = m(enc.to(dev), t2, caps.to(dev), caplens.to(dev))
+    _ok(preds, pr, TOL_OUT, "eval-mode preds")
+    loss, _, _ = R.caption_loss(preds, caps_s, dl2, alphas, 1.0)
+    loss.backward()
+    _ok(t2.grad, t1.grad, TOL_GRAD, "dtags")
+
+
+def test_pure_attention_full_width(dev):
+    """BASELINE config 1 shape (PureAttention, B=4, max_len 20 -> T=21) at the real widths, V reduced."""
+    from oracle import scnattn_ref as R
+    from models.decoders.pure_attention import PureAttention
+    torch.manual_seed(5)
+    B, V, L = 4, 300, 22
+    m = PureAttention(512, 512, 512, V, dropout=0.0)
+    g = torch.Generator().manual_seed(6)
+    enc = torch.rand(B, 14, 14, 2048, generator=g)
+    lens = torch.tensor([22, 15, 19, 9])
+    caps = torch.randint(1, V - 3, (B, L), generator=g)
+    caplens = lens.unsqueeze(1)
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    pr, cs, dl, al, si = R.pure_attention_forward(P, enc, caps, caplens)
+    loss_r, _, _ = R.caption_loss(pr, cs, dl, al, 1.0)
+    loss_r.backward()
+    m = m.to(dev).train()
+    preds, caps_s, dl2, alphas, _ = m(enc.to(dev), caps.to(dev), caplens.to(dev))
+    _ok(preds, pr, TOL_OUT, "preds"); _ok(alphas, al, TOL_OUT, "alphas")
+    loss, _, _ = R.caption_loss(preds, caps_s, dl2, alphas, 1.0)
+    loss.backward()
+    floors = {k: 1e-2 for k in P if k.startswith("attention.encoder_att") or k.startswith("attention.decoder_att")}
+    _check_grads(m.named_parameters(), lambda k: P[k].grad, 1e-3, floors)
+
+
+def test_argument_errors_surface_as_runtime_errors(dev):
+    """Limits of the LDS staging are reported through the C ABI's error channel, not by a fault."""
+    from scnattn._lib import call, ptr, stream_of
+    x = torch.zeros(8, device=dev)
+    with pytest.raises(RuntimeError, match="attention_dim too large"):
+        call("scnattn_attn_scores", stream_of(x), 1, 4, 1 << 16, ptr(x), ptr(x), 1, 0, 1 << 16, None, ptr(x), None, ptr(x), None)
+    with pytest.raises(RuntimeError, match="K must be >= 1"):
+        call("scnattn_sgemm", stream_of(x), 0, 0, 2, 2, 0, 1.0, ptr(x), 2, ptr(x), 2, 0.0, ptr(x), 2, None, None, 1, 0, 0, 0)
+    from models.decoders.attention_scn import AttentionSCN
+    m = AttentionSCN(8, 8, 8, 8, 4, 12, encoder_dim=8, dropout=0.0).to(dev)
+    with pytest.raises(RuntimeError):   # a caption of length 1 would decode 0 steps
+        m(torch.rand(2, 2, 2, 8, device=dev), torch.rand(2, 4, device=dev), torch.zeros(2, 4, dtype=torch.long, device=dev),
+          torch.tensor([[3], [1]], device=dev))
