@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--ksplit", type=int, default=0)
     ap.add_argument("--with-tagger", action="store_true",
                     help="also run the frozen EncoderTagger ResNet-152 each step (the reference's real step)")
+    ap.add_argument("--encoder-dtype", default="f32", choices=["f32", "bf16"],
+                    help="bf16: ResNet trunk under bf16 autocast (BASELINE config 5 flavour; not the fp32 headline)")
     ap.add_argument("--force-dist", action="store_true",
                     help="diagnostics: run the multi-rank code path (RCCL group, barriers, reducers) with one rank")
     ap.add_argument("--forward-only", action="store_true", help="diagnostics: decoder forward only (PMC passes)")
@@ -156,7 +158,8 @@ def main():
             warm_miopen(dev, args.batch, fine_tune)      # no collective inside
         dist.barrier()                                    # first collective on every rank
     ts = TrainStep(kind=args.workload, fine_tune_encoder=fine_tune, device=dev, encoder=not args.decoder_only,
-                   batch_size=args.batch, max_len=args.max_len, graph_encoder=args.graph, tagger=args.with_tagger, force_reduce=args.force_dist)
+                   batch_size=args.batch, max_len=args.max_len, graph_encoder=args.graph, tagger=args.with_tagger, force_reduce=args.force_dist,
+                   encoder_dtype=args.encoder_dtype)
     cfg = ts.cfg
     imgs, tags, caps, caplens = synthetic_batch(args.batch, cfg["vocab_size"], cfg["max_len"], cfg["image_size"],
                                                 cfg["semantic_dim"], dev, 1234 + rank)
@@ -213,7 +216,9 @@ def main():
             else "images/sec (train step, %s, bs%d/GPU)" % (args.workload, args.batch),
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f32" if args.encoder_dtype == "f32" else "bf16 encoder convs (fp32 accumulate/master) + f32 decoder",
+            "data": "synthetic",
             "config": {"workload": "%s decoder (emb/att/factor/dec=512, 1000 tags, V=%d, T=%d)%s, bs=%d/GPU, "
                                    "256x256 images, fp32" % (args.workload, cfg["vocab_size"], T,
                                                              " decoder only" if args.decoder_only else

@@ -168,13 +168,15 @@ int scnattn_pool_permute_bwd(void* stream, int B, int C, int Hin, int Win, int H
  *   bn_apply : y = relu?(gamma*(z-mean)*invstd + beta + res?)
  *   bn_bwd   : dbeta, dgamma, dz (batch-stat form when train != 0) and dres = dy*[y>0] */
 int scnattn_bn_workspace_floats(int C);
-int scnattn_bn_stats(void* stream, int R, int C, const float* x, float eps, float momentum, float* partial,
+/* bf16 != 0: the feature maps (x, z, res, y, dy, dz, dres) are bf16 in memory (trunk under bf16 autocast,
+ * BASELINE config 5); statistics, parameters and arithmetic stay fp32. */
+int scnattn_bn_stats(void* stream, int R, int C, const void* x, int bf16, float eps, float momentum, float* partial,
                      float* mean, float* invstd, float* run_mean, float* run_var);
-int scnattn_bn_apply(void* stream, int R, int C, const float* z, const float* res, const float* mean,
-                     const float* invstd, const float* gamma, const float* beta, int relu, float* y);
-int scnattn_bn_bwd(void* stream, int R, int C, const float* dy, const float* y, const float* z, const float* mean,
-                   const float* invstd, const float* gamma, int relu, int train, float* partial, float* dbeta,
-                   float* dgamma, float* dz, float* dres);
+int scnattn_bn_apply(void* stream, int R, int C, const void* z, const void* res, int bf16, const float* mean,
+                     const float* invstd, const float* gamma, const float* beta, int relu, void* y);
+int scnattn_bn_bwd(void* stream, int R, int C, const void* dy, const void* y, const void* z, int bf16,
+                   const float* mean, const float* invstd, const float* gamma, int relu, int train, float* partial,
+                   float* dbeta, float* dgamma, void* dz, void* dres);
 /* utils/optimizer.py:1-11 (element-wise clamp) fused with torch.optim.Adam's update
  * (trains/attention_scn.py:244-252); g is first scaled by gscale (1/world for data parallel). */
 int scnattn_clamp_adam(void* stream, long n, float* p, const float* g, float* m, float* v, double lr,

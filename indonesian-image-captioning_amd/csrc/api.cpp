@@ -186,20 +186,20 @@ int scnattn_pool_permute_bwd(void* stream, int B, int C, int Hin, int Win, int H
 
 int scnattn_bn_workspace_floats(int C) { return bn_max_chunks() * 2 * C; }
 
-int scnattn_bn_stats(void* stream, int R, int C, const float* x, float eps, float momentum, float* partial,
+int scnattn_bn_stats(void* stream, int R, int C, const void* x, int bf16, float eps, float momentum, float* partial,
                      float* mean, float* invstd, float* run_mean, float* run_var) {
-    return bn_stats(ST(stream), R, C, x, eps, momentum, partial, mean, invstd, run_mean, run_var);
+    return bn_stats(ST(stream), R, C, x, bf16, eps, momentum, partial, mean, invstd, run_mean, run_var);
 }
 
-int scnattn_bn_apply(void* stream, int R, int C, const float* z, const float* res, const float* mean,
-                     const float* invstd, const float* gamma, const float* beta, int relu, float* y) {
-    return bn_apply(ST(stream), R, C, z, res, mean, invstd, gamma, beta, relu, y);
+int scnattn_bn_apply(void* stream, int R, int C, const void* z, const void* res, int bf16, const float* mean,
+                     const float* invstd, const float* gamma, const float* beta, int relu, void* y) {
+    return bn_apply(ST(stream), R, C, z, res, bf16, mean, invstd, gamma, beta, relu, y);
 }
 
-int scnattn_bn_bwd(void* stream, int R, int C, const float* dy, const float* y, const float* z, const float* mean,
-                   const float* invstd, const float* gamma, int relu, int train, float* partial, float* dbeta,
-                   float* dgamma, float* dz, float* dres) {
-    return bn_bwd(ST(stream), R, C, dy, y, z, mean, invstd, gamma, relu, train, partial, dbeta, dgamma, dz, dres);
+int scnattn_bn_bwd(void* stream, int R, int C, const void* dy, const void* y, const void* z, int bf16,
+                   const float* mean, const float* invstd, const float* gamma, int relu, int train, float* partial,
+                   float* dbeta, float* dgamma, void* dz, void* dres) {
+    return bn_bwd(ST(stream), R, C, dy, y, z, bf16, mean, invstd, gamma, relu, train, partial, dbeta, dgamma, dz, dres);
 }
 
 int scnattn_clamp_adam(void* stream, long n, float* p, const float* g, float* m, float* v, double lr,

@@ -18,8 +18,29 @@ namespace scn {
 
 namespace {
 
+// Storage type of the feature maps: float, or bf16 when the trunk runs under bf16 autocast (BASELINE
+// config 5).  Arithmetic and statistics are fp32 either way.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+template <typename T> struct IO;
+template <> struct IO<float> {
+    static __device__ __forceinline__ f32x4 ld(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ void st(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+    static __device__ __forceinline__ float ld1(const float* p) { return *p; }
+};
+template <> struct IO<__bf16> {
+    static __device__ __forceinline__ f32x4 ld(const __bf16* p) {
+        const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+        return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    }
+    static __device__ __forceinline__ void st(__bf16* p, f32x4 v) {
+        *reinterpret_cast<bf16x4*>(p) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    }
+    static __device__ __forceinline__ float ld1(const __bf16* p) { return (float)*p; }
+};
+
 // partial[chunk][2][C]: shifted sums S1 = sum(x - s), S2 = sum((x - s)^2), s = x[0][c]
-__global__ __launch_bounds__(256) void bn_stats_kernel(int R, int C, int rows_per_chunk, const float* __restrict__ x,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(int R, int C, int rows_per_chunk, const T* __restrict__ x,
                                                        float* __restrict__ partial) {
     __shared__ float red[16][2][64 + 1];
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
@@ -27,12 +48,12 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(int R, int C, int rows_pe
     const int r0 = blockIdx.y * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
     float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     if (c < C) {
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(x + c);
+        const f32x4 sh = IO<T>::ld(x + c);
         int r = r0 + rl;
         for (; r + 48 < r1; r += 64) {
             f32x4 v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4*>(x + (long)(r + 16 * j) * C + c);
+            for (int j = 0; j < 4; ++j) v[j] = IO<T>::ld(x + (long)(r + 16 * j) * C + c);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -43,7 +64,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(int R, int C, int rows_pe
                 }
         }
         for (; r < r1; r += 16) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (long)r * C + c);
+            const f32x4 v = IO<T>::ld(x + (long)r * C + c);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float d = v[k] - sh[k];
@@ -96,7 +117,8 @@ __device__ __forceinline__ void reduce_partials16(const float* __restrict__ part
     }
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(int R, int C, int nchunk, const float* __restrict__ x,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_finalize_kernel(int R, int C, int nchunk, const T* __restrict__ x,
                                                           const float* __restrict__ partial, float eps, float momentum,
                                                           float* __restrict__ mean, float* __restrict__ invstd,
                                                           float* __restrict__ run_mean, float* __restrict__ run_var) {
@@ -107,7 +129,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(int R, int C, int nchu
     if (lane16 != 0 || c >= C) return;
     const float inv_n = 1.f / (float)R;
     const float m1 = s1 * inv_n;
-    const float mu = x[c] + m1;
+    const float mu = IO<T>::ld1(x + c) + m1;
     float var = s2 * inv_n - m1 * m1;
     if (var < 0.f) var = 0.f;
     mean[c] = mu;
@@ -119,21 +141,21 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(int R, int C, int nchu
     }
 }
 
-template <bool RELU, bool RES>
-__global__ __launch_bounds__(256) void bn_apply_kernel(long n4, int C, const float* __restrict__ z,
-                                                       const float* __restrict__ res, const float* __restrict__ mean,
+template <typename T, bool RELU, bool RES>
+__global__ __launch_bounds__(256) void bn_apply_kernel(long n4, int C, const T* __restrict__ z,
+                                                       const T* __restrict__ res, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, float* __restrict__ y) {
+                                                       const float* __restrict__ beta, T* __restrict__ y) {
     const int C4 = C >> 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const int c = (int)(i % C4) * 4;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(z + i * 4);
+        const f32x4 v = IO<T>::ld(z + i * 4);
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
         const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c);
         const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
         const f32x4 be = *reinterpret_cast<const f32x4*>(beta + c);
         f32x4 rr = {0.f, 0.f, 0.f, 0.f};
-        if (RES) rr = *reinterpret_cast<const f32x4*>(res + i * 4);
+        if (RES) rr = IO<T>::ld(res + i * 4);
         f32x4 o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -142,14 +164,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(long n4, int C, const flo
             if (RELU) t = fmaxf(t, 0.f);
             o[k] = t;
         }
-        *reinterpret_cast<f32x4*>(y + i * 4) = o;
+        IO<T>::st(y + i * 4, o);
     }
 }
 
 // partial[chunk][2][C]: sum g, sum g*xhat, g = dy * [y > 0] (RELU) or dy
-template <bool RELU>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(int R, int C, int rows_per_chunk, const float* __restrict__ dy,
-                                                            const float* __restrict__ y, const float* __restrict__ z,
+template <typename T, bool RELU>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(int R, int C, int rows_per_chunk, const T* __restrict__ dy,
+                                                            const T* __restrict__ y, const T* __restrict__ z,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             float* __restrict__ partial) {
     __shared__ float red[16][2][64 + 1];
@@ -168,9 +190,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(int R, int C, int ro
                 const int rr = r + 16 * j;
                 ok[j] = rr < r1;
                 const long off = (long)min(rr, r1 - 1) * C + c;
-                g[j] = *reinterpret_cast<const f32x4*>(dy + off);
-                zz[j] = *reinterpret_cast<const f32x4*>(z + off);
-                if (RELU) yy[j] = *reinterpret_cast<const f32x4*>(y + off);
+                g[j] = IO<T>::ld(dy + off);
+                zz[j] = IO<T>::ld(z + off);
+                if (RELU) yy[j] = IO<T>::ld(y + off);
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -213,20 +235,20 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int C, int nchunk,
 }
 
 // TRAIN: dz = gamma*invstd*(g - dbeta/R - xhat*dgamma/R); eval: dz = gamma*invstd*g.  dres = g.
-template <bool RELU, bool TRAIN>
-__global__ __launch_bounds__(256) void bn_bwd_dx_kernel(long n4, int R, int C, const float* __restrict__ dy,
-                                                        const float* __restrict__ y, const float* __restrict__ z,
+template <typename T, bool RELU, bool TRAIN>
+__global__ __launch_bounds__(256) void bn_bwd_dx_kernel(long n4, int R, int C, const T* __restrict__ dy,
+                                                        const T* __restrict__ y, const T* __restrict__ z,
                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ dbeta,
-                                                        const float* __restrict__ dgamma, float* __restrict__ dz,
-                                                        float* __restrict__ dres) {
+                                                        const float* __restrict__ dgamma, T* __restrict__ dz,
+                                                        T* __restrict__ dres) {
     const int C4 = C >> 2;
     const float inv_n = 1.f / (float)R;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const int c = (int)(i % C4) * 4;
-        f32x4 g = *reinterpret_cast<const f32x4*>(dy + i * 4);
+        f32x4 g = IO<T>::ld(dy + i * 4);
         if (RELU) {
-            const f32x4 yy = *reinterpret_cast<const f32x4*>(y + i * 4);
+            const f32x4 yy = IO<T>::ld(y + i * 4);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (!(yy[k] > 0.f)) g[k] = 0.f;
@@ -235,7 +257,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(long n4, int R, int C, c
         const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
         f32x4 o;
         if (TRAIN) {
-            const f32x4 zz = *reinterpret_cast<const f32x4*>(z + i * 4);
+            const f32x4 zz = IO<T>::ld(z + i * 4);
             const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
             const f32x4 db = *reinterpret_cast<const f32x4*>(dbeta + c);
             const f32x4 dg = *reinterpret_cast<const f32x4*>(dgamma + c);
@@ -248,8 +270,8 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(long n4, int R, int C, c
 #pragma unroll
             for (int k = 0; k < 4; ++k) o[k] = ga[k] * is[k] * g[k];
         }
-        if (dz) *reinterpret_cast<f32x4*>(dz + i * 4) = o;
-        if (dres) *reinterpret_cast<f32x4*>(dres + i * 4) = g;
+        if (dz) IO<T>::st(dz + i * 4, o);
+        if (dres) IO<T>::st(dres + i * 4, g);
     }
 }
 
@@ -276,27 +298,34 @@ inline unsigned ew_blocks(long n4) {
 
 int bn_max_chunks() { return 256; }
 
-int bn_stats(hipStream_t st, int R, int C, const float* x, float eps, float momentum, float* partial, float* mean,
-             float* invstd, float* run_mean, float* run_var) {
-    SCN_ARG(R > 0 && C > 0 && C % 4 == 0 && x && partial && mean && invstd, "bn_stats: bad argument");
-    SCN_ARG(aligned16(x), "bn_stats: x must be 16-byte aligned");
+template <typename T>
+static int bn_stats_t(hipStream_t st, int R, int C, const T* x, float eps, float momentum, float* partial, float* mean,
+                      float* invstd, float* run_mean, float* run_var) {
     int rpc;
     const int nchunk = pick_chunks(R, C, &rpc);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(cdiv(C, 64), nchunk), dim3(256), 0, st, R, C, rpc, x, partial);
+    hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(cdiv(C, 64), nchunk), dim3(256), 0, st, R, C, rpc, x, partial);
     SCN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, R, C, nchunk, x, partial, eps,
+    hipLaunchKernelGGL(bn_finalize_kernel<T>, dim3(cdiv(C, 16)), dim3(256), 0, st, R, C, nchunk, x, partial, eps,
                        momentum, mean, invstd, run_mean, run_var);
     SCN_LAUNCH_CHECK();
     return 0;
 }
 
-int bn_apply(hipStream_t st, int R, int C, const float* z, const float* res, const float* mean, const float* invstd,
-             const float* gamma, const float* beta, int relu, float* y) {
-    SCN_ARG(R > 0 && C > 0 && C % 4 == 0 && z && mean && invstd && gamma && beta && y, "bn_apply: bad argument");
+int bn_stats(hipStream_t st, int R, int C, const void* x, int bf16, float eps, float momentum, float* partial,
+             float* mean, float* invstd, float* run_mean, float* run_var) {
+    SCN_ARG(R > 0 && C > 0 && C % 4 == 0 && x && partial && mean && invstd, "bn_stats: bad argument");
+    SCN_ARG((reinterpret_cast<uintptr_t>(x) & (bf16 ? 7u : 15u)) == 0, "bn_stats: x is not vector aligned");
+    if (bf16) return bn_stats_t<__bf16>(st, R, C, (const __bf16*)x, eps, momentum, partial, mean, invstd, run_mean, run_var);
+    return bn_stats_t<float>(st, R, C, (const float*)x, eps, momentum, partial, mean, invstd, run_mean, run_var);
+}
+
+template <typename T>
+static int bn_apply_t(hipStream_t st, int R, int C, const T* z, const T* res, const float* mean, const float* invstd,
+                      const float* gamma, const float* beta, int relu, T* y) {
     const long n4 = (long)R * C / 4;
     dim3 grid(ew_blocks(n4)), block(256);
 #define SCN_BN_APPLY(RELU_, RES_) \
-    hipLaunchKernelGGL((bn_apply_kernel<RELU_, RES_>), grid, block, 0, st, n4, C, z, res, mean, invstd, gamma, beta, y)
+    hipLaunchKernelGGL((bn_apply_kernel<T, RELU_, RES_>), grid, block, 0, st, n4, C, z, res, mean, invstd, gamma, beta, y)
     if (relu && res) SCN_BN_APPLY(true, true);
     else if (relu) SCN_BN_APPLY(true, false);
     else if (res) SCN_BN_APPLY(false, true);
@@ -306,25 +335,30 @@ int bn_apply(hipStream_t st, int R, int C, const float* z, const float* res, con
     return 0;
 }
 
-int bn_bwd(hipStream_t st, int R, int C, const float* dy, const float* y, const float* z, const float* mean,
-           const float* invstd, const float* gamma, int relu, int train, float* partial, float* dbeta, float* dgamma,
-           float* dz, float* dres) {
-    SCN_ARG(R > 0 && C > 0 && C % 4 == 0 && dy && z && mean && invstd && gamma && partial && dbeta && dgamma,
-            "bn_bwd: bad argument");
-    SCN_ARG(!relu || y, "bn_bwd: relu needs the forward output");
+int bn_apply(hipStream_t st, int R, int C, const void* z, const void* res, int bf16, const float* mean,
+             const float* invstd, const float* gamma, const float* beta, int relu, void* y) {
+    SCN_ARG(R > 0 && C > 0 && C % 4 == 0 && z && mean && invstd && gamma && beta && y, "bn_apply: bad argument");
+    if (bf16) return bn_apply_t<__bf16>(st, R, C, (const __bf16*)z, (const __bf16*)res, mean, invstd, gamma, beta, relu, (__bf16*)y);
+    return bn_apply_t<float>(st, R, C, (const float*)z, (const float*)res, mean, invstd, gamma, beta, relu, (float*)y);
+}
+
+template <typename T>
+static int bn_bwd_t(hipStream_t st, int R, int C, const T* dy, const T* y, const T* z, const float* mean,
+                    const float* invstd, const float* gamma, int relu, int train, float* partial, float* dbeta,
+                    float* dgamma, T* dz, T* dres) {
     int rpc;
     const int nchunk = pick_chunks(R, C, &rpc);
     dim3 rgrid(cdiv(C, 64), nchunk), block(256);
-    if (relu) hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, rgrid, block, 0, st, R, C, rpc, dy, y, z, mean, invstd, partial);
-    else      hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, rgrid, block, 0, st, R, C, rpc, dy, y, z, mean, invstd, partial);
+    if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), rgrid, block, 0, st, R, C, rpc, dy, y, z, mean, invstd, partial);
+    else      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), rgrid, block, 0, st, R, C, rpc, dy, y, z, mean, invstd, partial);
     SCN_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), block, 0, st, C, nchunk, partial, dbeta, dgamma);
     SCN_LAUNCH_CHECK();
     if (dz || dres) {
         const long n4 = (long)R * C / 4;
         dim3 grid(ew_blocks(n4));
-#define SCN_BN_DX(RELU_, TRAIN_)                                                                                  \
-    hipLaunchKernelGGL((bn_bwd_dx_kernel<RELU_, TRAIN_>), grid, block, 0, st, n4, R, C, dy, y, z, mean, invstd, gamma, \
+#define SCN_BN_DX(RELU_, TRAIN_)                                                                                     \
+    hipLaunchKernelGGL((bn_bwd_dx_kernel<T, RELU_, TRAIN_>), grid, block, 0, st, n4, R, C, dy, y, z, mean, invstd, gamma, \
                        dbeta, dgamma, dz, dres)
         if (relu && train) SCN_BN_DX(true, true);
         else if (relu) SCN_BN_DX(true, false);
@@ -334,6 +368,18 @@ int bn_bwd(hipStream_t st, int R, int C, const float* dy, const float* y, const 
         SCN_LAUNCH_CHECK();
     }
     return 0;
+}
+
+int bn_bwd(hipStream_t st, int R, int C, const void* dy, const void* y, const void* z, int bf16, const float* mean,
+           const float* invstd, const float* gamma, int relu, int train, float* partial, float* dbeta, float* dgamma,
+           void* dz, void* dres) {
+    SCN_ARG(R > 0 && C > 0 && C % 4 == 0 && dy && z && mean && invstd && gamma && partial && dbeta && dgamma,
+            "bn_bwd: bad argument");
+    SCN_ARG(!relu || y, "bn_bwd: relu needs the forward output");
+    if (bf16) return bn_bwd_t<__bf16>(st, R, C, (const __bf16*)dy, (const __bf16*)y, (const __bf16*)z, mean, invstd, gamma, relu, train,
+                                      partial, dbeta, dgamma, (__bf16*)dz, (__bf16*)dres);
+    return bn_bwd_t<float>(st, R, C, (const float*)dy, (const float*)y, (const float*)z, mean, invstd, gamma, relu, train, partial,
+                           dbeta, dgamma, (float*)dz, (float*)dres);
 }
 
 }  // namespace scn

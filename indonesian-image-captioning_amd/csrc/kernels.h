@@ -90,12 +90,12 @@ int reduce_slabs(hipStream_t st, int rows, int N, Slabs s, float* out);
 
 // ---- batchnorm.hip (channels-last feature maps as [R = N*H*W, C] matrices) --------------------------
 int bn_max_chunks();
-int bn_stats(hipStream_t st, int R, int C, const float* x, float eps, float momentum, float* partial, float* mean,
-             float* invstd, float* run_mean, float* run_var);
-int bn_apply(hipStream_t st, int R, int C, const float* z, const float* res, const float* mean, const float* invstd,
-             const float* gamma, const float* beta, int relu, float* y);
-int bn_bwd(hipStream_t st, int R, int C, const float* dy, const float* y, const float* z, const float* mean,
+int bn_stats(hipStream_t st, int R, int C, const void* x, int bf16, float eps, float momentum, float* partial,
+             float* mean, float* invstd, float* run_mean, float* run_var);
+int bn_apply(hipStream_t st, int R, int C, const void* z, const void* res, int bf16, const float* mean,
+             const float* invstd, const float* gamma, const float* beta, int relu, void* y);
+int bn_bwd(hipStream_t st, int R, int C, const void* dy, const void* y, const void* z, int bf16, const float* mean,
            const float* invstd, const float* gamma, int relu, int train, float* partial, float* dbeta, float* dgamma,
-           float* dz, float* dres);
+           void* dz, void* dres);
 
 }  // namespace scn

@@ -352,7 +352,8 @@ class _PoolPermute(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, out_size):
         require_cuda(x)
-        if x.dtype != torch.float32:
+        ctx.in_dtype = x.dtype
+        if x.dtype != torch.float32:     # bf16 trunk: the decoder side is fp32
             x = x.float()
         B, Cn, Hin, Win = x.shape
         y = torch.empty((B, out_size, out_size, Cn), device=x.device, dtype=torch.float32)
@@ -370,7 +371,7 @@ class _PoolPermute(torch.autograd.Function):
                          memory_format=torch.channels_last if ctx.channels_last else torch.contiguous_format)
         sb, scs, sh, sw = dx.stride()
         call("scnattn_pool_permute_bwd", stream_of(dy), B, Cn, Hin, Win, out_size, out_size, ptr(dy), ptr(dx), sb, scs, sh, sw)
-        return dx, None
+        return (dx if ctx.in_dtype == torch.float32 else dx.to(ctx.in_dtype)), None
 
 
 def pool_permute(x, out_size):
@@ -404,16 +405,19 @@ def _bn_fns():
 
 
 class _BNAct(torch.autograd.Function):
+    """Feature maps may be fp32 or bf16 (trunk under bf16 autocast); parameters/statistics are fp32."""
+
     @staticmethod
     def forward(ctx, z, res, gamma, beta, run_mean, run_var, training, momentum, eps, relu):
         if not z.is_cuda:
             raise RuntimeError("scnattn: fused BatchNorm needs tensors on an MI355X device; there is no CPU fallback")
-        if z.dtype != torch.float32:
+        if z.dtype not in (torch.float32, torch.bfloat16):
             z = z.float()
+        bf16 = 1 if z.dtype == torch.bfloat16 else 0
         if not z.is_contiguous(memory_format=torch.channels_last):
             z = z.contiguous(memory_format=torch.channels_last)
-        if res is not None and (res.dtype != torch.float32 or not res.is_contiguous(memory_format=torch.channels_last)):
-            res = res.float().contiguous(memory_format=torch.channels_last)
+        if res is not None and (res.dtype != z.dtype or not res.is_contiguous(memory_format=torch.channels_last)):
+            res = res.to(z.dtype).contiguous(memory_format=torch.channels_last)
         N, Cn, H, W = z.shape
         R = N * H * W
         f_stats, f_apply, _, raw_stream = _bn_fns()
@@ -421,36 +425,36 @@ class _BNAct(torch.autograd.Function):
         if training:
             stats = torch.empty((2, Cn), device=z.device, dtype=torch.float32)
             mean, invstd = stats[0], stats[1]
-            rc = f_stats(st, R, Cn, z.data_ptr(), eps, momentum, _bn_workspace(z.device, Cn).data_ptr(),
+            rc = f_stats(st, R, Cn, z.data_ptr(), bf16, eps, momentum, _bn_workspace(z.device, Cn).data_ptr(),
                          mean.data_ptr(), invstd.data_ptr(), run_mean.data_ptr(), run_var.data_ptr())
             if rc:
                 _lib.check(rc, "scnattn_bn_stats")
         else:
             mean, invstd = run_mean.float(), torch.rsqrt(run_var.float() + eps)
         y = torch.empty_like(z)   # preserves the channels-last strides
-        rc = f_apply(st, R, Cn, z.data_ptr(), None if res is None else res.data_ptr(), mean.data_ptr(),
+        rc = f_apply(st, R, Cn, z.data_ptr(), None if res is None else res.data_ptr(), bf16, mean.data_ptr(),
                      invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), int(relu), y.data_ptr())
         if rc:
             _lib.check(rc, "scnattn_bn_apply")
         ctx.save_for_backward(z, y if relu else None, mean, invstd, gamma)
-        ctx.cfg = (bool(training), bool(relu), res is not None)
+        ctx.cfg = (bool(training), bool(relu), res is not None, bf16)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         z, y, mean, invstd, gamma = ctx.saved_tensors
-        training, relu, has_res = ctx.cfg
+        training, relu, has_res, bf16 = ctx.cfg
         N, Cn, H, W = z.shape
         R = N * H * W
-        if dy.dtype != torch.float32 or not dy.is_contiguous(memory_format=torch.channels_last):
-            dy = dy.float().contiguous(memory_format=torch.channels_last)
+        if dy.dtype != z.dtype or not dy.is_contiguous(memory_format=torch.channels_last):
+            dy = dy.to(z.dtype).contiguous(memory_format=torch.channels_last)
         need = ctx.needs_input_grad
         dz = torch.empty_like(z) if need[0] else None
         dres = torch.empty_like(z) if (has_res and need[1]) else None
         dgb = torch.empty((2, Cn), device=z.device, dtype=torch.float32)
         _, _, f_bwd, raw_stream = _bn_fns()
         rc = f_bwd(raw_stream(z.device.index), R, Cn, dy.data_ptr(), None if y is None else y.data_ptr(), z.data_ptr(),
-                   mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), int(relu), int(training),
+                   bf16, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), int(relu), int(training),
                    _bn_workspace(z.device, Cn).data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
                    None if dz is None else dz.data_ptr(), None if dres is None else dres.data_ptr())
         if rc:

@@ -58,10 +58,15 @@ def build_decoder(kind, cfg):
 
 class TrainStep:
     def __init__(self, kind="attention_scn", fine_tune_encoder=True, device="cuda", seed=1234, encoder=True,
-                 bucket_mb=32, graph_encoder=False, tagger=False, force_reduce=False, **overrides):
+                 bucket_mb=32, graph_encoder=False, tagger=False, force_reduce=False, encoder_dtype="f32",
+                 **overrides):
         self.cfg = dict(DEFAULTS)
         self.cfg.update(overrides)
         self.kind = kind
+        # "bf16": the ResNet trunk runs under bf16 autocast (MIOpen bf16 MFMA convolutions, bf16 feature maps
+        # through the fused BatchNorm kernels, fp32 master weights/statistics); the decoder stays fp32.
+        # This is BASELINE config 5's mixed-precision flavour, NOT the headline fp32 metric.
+        self.encoder_bf16 = encoder_dtype == "bf16"
         self.device = torch.device(device)
         torch.manual_seed(seed)  # same seed on every rank => identical initial weights
         self.decoder = build_decoder(kind, self.cfg).to(self.device)
@@ -118,10 +123,13 @@ class TrainStep:
         return loss
 
     def step(self, imgs, tags, caps, caplens, encoder_out=None):
-        if self.encoder is not None:
-            encoder_out = self.encoder_call(imgs)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.encoder_bf16):
+            if self.encoder is not None:
+                encoder_out = self.encoder_call(imgs)
+            if self.tagger is not None:
+                tags = self.tagger(imgs)
         if self.tagger is not None:
-            tags = self.tagger(imgs)
+            tags = tags.float()
         if self.kind == "attention_scn":
             scores, caps_sorted, decode_lengths, alphas, _ = self.decoder(encoder_out, tags, caps, caplens)
         elif self.kind == "pure_scn":

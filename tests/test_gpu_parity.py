@@ -754,3 +754,39 @@ def test_argument_errors_surface_as_runtime_errors(dev):
     with pytest.raises(RuntimeError):   # a caption of length 1 would decode 0 steps
         m(torch.rand(2, 2, 2, 8, device=dev), torch.rand(2, 4, device=dev), torch.zeros(2, 4, dtype=torch.long, device=dev),
           torch.tensor([[3], [1]], device=dev))
+
+
+@pytest.mark.parametrize("training,with_res", [(True, True), (True, False), (False, True)])
+def test_fused_batchnorm_bf16_storage(dev, training, with_res):
+    """bf16 feature maps through the fused BatchNorm kernels (trunk under bf16 autocast, BASELINE config 5):
+    fp32 statistics/arithmetic, so the only error is the bf16 rounding of inputs/outputs (2^-8 relative)."""
+    from scnattn.resnet import FusedBatchNorm2d
+    torch.manual_seed(11)
+    N, C, H, W = 8, 128, 12, 12
+    x = (torch.randn(N, C, H, W) * 1.5 + 0.4).bfloat16()
+    res = torch.randn(N, C, H, W).bfloat16() if with_res else None
+    wgt = torch.randn(N, C, H, W).bfloat16()
+    ref = torch.nn.BatchNorm2d(C).double()
+    with torch.no_grad():
+        ref.weight.uniform_(0.5, 1.5); ref.bias.normal_(0, 0.3)
+        ref.running_mean.normal_(0, 0.2); ref.running_var.uniform_(0.5, 2.0)
+    m = FusedBatchNorm2d(C)
+    m.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    m = m.to(dev)
+    ref.train(training); m.train(training)
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)
+    if with_res:
+        yr = yr + res.double()
+    yr = torch.relu(yr)
+    (yr * wgt.double()).sum().backward()
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    rd = res.to(dev).contiguous(memory_format=torch.channels_last) if with_res else None
+    y = m(xd, residual=rd, relu=True)
+    assert y.dtype == torch.bfloat16
+    _ok(y.float(), yr, 1e-2, "y")
+    (y.float() * wgt.to(dev).float()).sum().backward()
+    assert xd.grad.dtype == torch.bfloat16
+    _ok(xd.grad.float(), xr.grad, 2e-2, "dx")
+    _ok(m.weight.grad, ref.weight.grad, 1e-2, "dgamma"); _ok(m.bias.grad, ref.bias.grad, 1e-2, "dbeta")
+    _ok(m.running_mean, ref.running_mean, 1e-4, "running_mean"); _ok(m.running_var, ref.running_var, 1e-4, "running_var")
