@@ -21,6 +21,7 @@ const char* last_error() { return g_err; }
 
 extern int g_ksplit_scale;
 extern int g_profile;
+extern int g_fuse_attn;
 int profile_collect(double* out);
 int seq_workspace(const scnattn_dims* d, size_t* saved_bytes, size_t* scratch_bytes);
 int seq_fwd(hipStream_t st, const scnattn_dims* d, const scnattn_params* w, const float* enc, const float* tags,
@@ -44,6 +45,10 @@ const char* scnattn_last_error(void) { return last_error(); }
 int scnattn_set_option(const char* name, int value) {
     if (name && std::strcmp(name, "ksplit") == 0) {
         g_ksplit_scale = value;
+        return 0;
+    }
+    if (name && std::strcmp(name, "fuse_attn") == 0) {
+        g_fuse_attn = value;
         return 0;
     }
     if (name && std::strcmp(name, "profile") == 0) {

@@ -197,6 +197,130 @@ __global__ __launch_bounds__(512) void attn_context_kernel(int rows, int P, int 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused scores + softmax + context + gate for the sequence path: one launch instead of two.
+// Grid (rows, E/256): the E-chunk workgroups of one batch row have consecutive-by-`rows` linear ids, so
+// with rows % 8 == 0 they land on the SAME XCD (workgroups are dealt round-robin over the 8 XCDs) and the
+// row's att1 slice (P*A floats, read by every chunk to recompute the P scores) is fetched from HBM once
+// and served to the other chunks by that XCD's L2.  Placement only affects speed, never correctness.
+__global__ __launch_bounds__(512) void attn_fused_kernel(int rows, int P, int E, int A, const float* __restrict__ enc,
+                                                         const float* __restrict__ att1, Slabs att2,
+                                                         const float* __restrict__ bd, const float* __restrict__ wf,
+                                                         const float* __restrict__ b0, Slabs gpre,
+                                                         const float* __restrict__ bbeta,
+                                                         float* __restrict__ alpha_out, long alpha_ld,
+                                                         float* __restrict__ alpha_save, float* __restrict__ att2_out,
+                                                         float* __restrict__ awe, float* __restrict__ gate,
+                                                         float* __restrict__ z) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* part = sm;                  // [8][256]
+    float* red = sm + 8 * 256;         // [16]
+    float* att2s = red + 16;           // [A]
+    float* ws = att2s + A;             // [A]
+    float* alph = ws + A;              // [P]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, e0 = blockIdx.y * 256;
+
+    // (0) first batch of encoder rows in flight (independent of everything below)
+    constexpr int CU = 8;
+    const int col = e0 + lane * 4;
+    const float* base = enc + (long)b * P * E;
+    const int cc = min(col, E - 4);
+    const bool cok = col < E;
+    f32x4 v[CU];
+#pragma unroll
+    for (int j = 0; j < CU; ++j) v[j] = *reinterpret_cast<const f32x4*>(base + (long)min(wave + 8 * j, P - 1) * E + cc);
+
+    // (1) att2 = sum(slabs) + bias, and the full_att vector, into LDS
+    for (int a = tid; a < A; a += 512) {
+        const float t2 = slab_sum(att2.p, (long)b * att2.ld + a, att2.n, att2.stride) + (bd ? bd[a] : 0.f);
+        att2s[a] = t2;
+        ws[a] = wf[a];
+        if (blockIdx.y == 0 && att2_out) att2_out[(long)b * A + a] = t2;
+    }
+    __syncthreads();
+
+    // (2) e[p] = w . relu(att1[b,p,:] + att2) + b0 for ALL pixels (each chunk recomputes them)
+    const float bias0 = b0 ? b0[0] : 0.f;
+    const float* a1 = att1 + (long)b * P * A;
+    for (int p0 = wave * 4; p0 < P; p0 += 32) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int a = lane * 4; a < A; a += 256) {
+            const f32x4 s2 = *reinterpret_cast<const f32x4*>(att2s + a);
+            const f32x4 ww = *reinterpret_cast<const f32x4*>(ws + a);
+            f32x4 t[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = *reinterpret_cast<const f32x4*>(a1 + (long)min(p0 + j, P - 1) * A + a);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[j] = fmaf(fmaxf(t[j][c] + s2[c], 0.f), ww[c], acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float sres = wave_sum(acc[j]);
+            if (lane == 0 && p0 + j < P) alph[p0 + j] = sres + bias0;
+        }
+    }
+    __syncthreads();
+
+    // (3) softmax over the P scores
+    float m = -INFINITY;
+    for (int p = tid; p < P; p += 512) m = fmaxf(m, alph[p]);
+    m = block_reduce(m, red, true);
+    float ssum = 0.f;
+    for (int p = tid; p < P; p += 512) {
+        const float ex = expf(alph[p] - m);
+        alph[p] = ex;
+        ssum += ex;
+    }
+    ssum = block_reduce(ssum, red, false);
+    for (int p = tid; p < P; p += 512) {
+        const float al = alph[p] / ssum;
+        alph[p] = al;
+        if (blockIdx.y == 0) {
+            if (alpha_out) alpha_out[(long)b * alpha_ld + p] = al;
+            if (alpha_save) alpha_save[(long)b * P + p] = al;
+        }
+    }
+    __syncthreads();
+
+    // (4) awe = sum_p alpha * enc over this chunk's 256 columns, then the sigmoid gate
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int p = wave;;) {
+        float al[CU];
+#pragma unroll
+        for (int j = 0; j < CU; ++j) {
+            const int pp = p + 8 * j;
+            al[j] = (pp < P && cok) ? alph[min(pp, P - 1)] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < CU; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = fmaf(al[j], v[j][c], acc[c]);
+        p += 8 * CU;
+        if (p >= P) break;
+#pragma unroll
+        for (int j = 0; j < CU; ++j) v[j] = *reinterpret_cast<const f32x4*>(base + (long)min(p + 8 * j, P - 1) * E + cc);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) part[wave * 256 + lane * 4 + c] = acc[c];
+    __syncthreads();
+    if (tid < 256) {
+        const int c = e0 + tid;
+        if (c < E) {
+            float a = part[tid];
+#pragma unroll
+            for (int w8 = 1; w8 < 8; ++w8) a += part[w8 * 256 + tid];
+            awe[(long)b * E + c] = a;
+            const float gp = slab_sum(gpre.p, (long)b * gpre.ld + c, gpre.n, gpre.stride) + (bbeta ? bbeta[c] : 0.f);
+            const float g = sigmoidf_(gp);
+            gate[(long)b * E + c] = g;
+            z[(long)b * E + c] = g * a;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 template <bool VEC>
 __global__ __launch_bounds__(256) void attn_dalpha_kernel(int rows, int P, int E, const float* __restrict__ enc,
                                                           const float* __restrict__ dawe,
@@ -482,5 +606,23 @@ int attn_datt1_post(hipStream_t st, int B, int P, int A, int T, const int* dl, c
 }
 
 int attn_datt1_post_blocks(int B, int P) { return cdiv(P, PC2) * B; }
+
+bool attn_fused_ok(int P, int E, int A, const float* enc, const float* att1) {
+    const size_t lds = (8 * 256 + 16 + 2 * (size_t)A + P) * sizeof(float);
+    return E % 4 == 0 && A % 4 == 0 && aligned16(enc) && aligned16(att1) && lds <= 64 * 1024;
+}
+
+int attn_fused(hipStream_t st, int rows, int P, int E, int A, const float* enc, const float* att1, Slabs att2,
+               const float* bd, const float* wf, const float* b0, Slabs gpre, const float* bbeta, float* alpha_out,
+               long alpha_ld, float* alpha_save, float* att2_out, float* awe, float* gate, float* z) {
+    if (rows <= 0) return 0;
+    SCN_ARG(enc && att1 && att2.p && wf && gpre.p && awe && gate && z, "attn_fused: null operand");
+    SCN_ARG(attn_fused_ok(P, E, A, enc, att1), "attn_fused: shape not supported (use attn_scores + attn_context)");
+    const size_t lds = (8 * 256 + 16 + 2 * (size_t)A + P) * sizeof(float);
+    hipLaunchKernelGGL(attn_fused_kernel, dim3(rows, cdiv(E, 256)), dim3(512), lds, st, rows, P, E, A, enc, att1, att2, bd,
+                       wf, b0, gpre, bbeta, alpha_out, alpha_ld, alpha_save, att2_out, awe, gate, z);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
 
 }  // namespace scn

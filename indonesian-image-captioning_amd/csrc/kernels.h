@@ -38,6 +38,12 @@ int attn_scores(hipStream_t st, int rows, int P, int A, const float* att1, Slabs
 int attn_context(hipStream_t st, int rows, int P, int E, const float* enc, const float* e, Slabs gpre,
                  const float* bbeta, float* alpha_out, long alpha_ld, float* alpha_save, float* awe,
                  float* gate, float* z);
+// scores + softmax + context + gate in ONE launch (sequence path); attn_fused_ok() says whether the shape
+// qualifies (16-byte alignment, LDS budget), otherwise use attn_scores + attn_context
+bool attn_fused_ok(int P, int E, int A, const float* enc, const float* att1);
+int attn_fused(hipStream_t st, int rows, int P, int E, int A, const float* enc, const float* att1, Slabs att2,
+               const float* bd, const float* wf, const float* b0, Slabs gpre, const float* bbeta, float* alpha_out,
+               long alpha_ld, float* alpha_save, float* att2_out, float* awe, float* gate, float* z);
 int mean_pixels(hipStream_t st, int rows, int P, int E, const float* enc, float* out);
 // dalpha[b,p] = enc[b,p,:] . dawe[b,:] + dalpha_in[b,p]
 int attn_dalpha(hipStream_t st, int rows, int P, int E, const float* enc, const float* dawe,

@@ -21,6 +21,8 @@ namespace scn {
 
 int g_ksplit_scale = 0;  // 0 = auto; >0 forces ksplit for every skinny launch (tuning/testing)
 int g_profile = 0;       // 1: bracket the recurrence loops with HIP events (scnattn_profile_collect)
+int g_fuse_attn = 0;     // 1: scores+softmax+context+gate as one launch (measured SLOWER: 54.0 vs 47.5 us/step,
+                         //    each E-chunk workgroup recomputes all 196 scores through its CU's L2 port)
 
 // ---- optional in-stream timing of the recurrence loops (bench.py's roofline figure) ------------------
 struct LoopEvent { hipEvent_t a, b; int kind, steps; };
@@ -268,14 +270,25 @@ int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
         SCN_TRY(skinny_gemm(st, bt_, NA, D, 1, h, D, 0, f.WcatA, NA, 0, f.slabA, NA, 0, (long)B * NA, ksA));
         Slabs pz{nullptr, 0, 0, 0};
         if (d.has_att) {
-            SCN_TRY(attn_scores(st, bt_, P, A, s.att1, Slabs{f.slabA, ksA, (long)B * NA, NA},
-                                w->attention_decoder_att_bias, w->attention_full_att_weight,
-                                w->attention_full_att_bias, f.e, s.att2_all + (long)t * B * A));
-            hipEvent_t evc = g_profile >= 2 ? prof_begin(st) : nullptr;   // per-launch timing of the dominant kernel
-            SCN_TRY(attn_context(st, bt_, P, E, enc, f.e, Slabs{f.slabA + A, ksA, (long)B * NA, NA}, w->f_beta_bias,
-                                 alphas + (long)t * P, (long)T * P, s.alpha_tm + (long)t * B * P,
-                                 s.awe_all + (long)t * B * E, s.gate_all + (long)t * B * E, s.z_all + (long)t * B * E));
-            prof_end(st, evc, 2, 1);
+            if (g_fuse_attn && attn_fused_ok(P, E, A, enc, s.att1)) {
+                hipEvent_t evc = g_profile >= 2 ? prof_begin(st) : nullptr;
+                SCN_TRY(attn_fused(st, bt_, P, E, A, enc, s.att1, Slabs{f.slabA, ksA, (long)B * NA, NA},
+                                   w->attention_decoder_att_bias, w->attention_full_att_weight,
+                                   w->attention_full_att_bias, Slabs{f.slabA + A, ksA, (long)B * NA, NA},
+                                   w->f_beta_bias, alphas + (long)t * P, (long)T * P, s.alpha_tm + (long)t * B * P,
+                                   s.att2_all + (long)t * B * A, s.awe_all + (long)t * B * E,
+                                   s.gate_all + (long)t * B * E, s.z_all + (long)t * B * E));
+                prof_end(st, evc, 2, 1);
+            } else {
+                SCN_TRY(attn_scores(st, bt_, P, A, s.att1, Slabs{f.slabA, ksA, (long)B * NA, NA},
+                                    w->attention_decoder_att_bias, w->attention_full_att_weight,
+                                    w->attention_full_att_bias, f.e, s.att2_all + (long)t * B * A));
+                hipEvent_t evc = g_profile >= 2 ? prof_begin(st) : nullptr;   // per-launch timing of the dominant kernel
+                SCN_TRY(attn_context(st, bt_, P, E, enc, f.e, Slabs{f.slabA + A, ksA, (long)B * NA, NA}, w->f_beta_bias,
+                                     alphas + (long)t * P, (long)T * P, s.alpha_tm + (long)t * B * P,
+                                     s.awe_all + (long)t * B * E, s.gate_all + (long)t * B * E, s.z_all + (long)t * B * E));
+                prof_end(st, evc, 2, 1);
+            }
             const int ksC = pick(bt_, F4, E, 1);
             SCN_TRY(skinny_gemm(st, bt_, F4, E, 1, s.z_all + (long)t * B * E, E, 0,
                                 w->decode_step_weight_ia + (long)M * F4, F4, 0, f.slabC, F4, 0, (long)B * F4, ksC));

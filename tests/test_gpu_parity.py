@@ -790,3 +790,29 @@ def test_fused_batchnorm_bf16_storage(dev, training, with_res):
     _ok(xd.grad.float(), xr.grad, 2e-2, "dx")
     _ok(m.weight.grad, ref.weight.grad, 1e-2, "dgamma"); _ok(m.bias.grad, ref.bias.grad, 1e-2, "dbeta")
     _ok(m.running_mean, ref.running_mean, 1e-4, "running_mean"); _ok(m.running_var, ref.running_var, 1e-4, "running_var")
+
+
+def test_fused_attention_option_matches_default_path(dev):
+    """Option fuse_attn (one launch for scores + softmax + context + gate) must give the same numbers as
+    the default two-launch path (it is off by default only because it measured slower)."""
+    from models.decoders.attention_scn import AttentionSCN
+    from scnattn import functional as SF
+    torch.manual_seed(12)
+    B, V, L = 8, 40, 7
+    m = AttentionSCN(32, 24, 32, 40, 12, V, encoder_dim=64, dropout=0.0).to(dev).train()
+    enc = torch.rand(B, 4, 4, 64, device=dev)
+    tags = torch.rand(B, 12, device=dev)
+    caps = torch.randint(1, V - 3, (B, L), device=dev)
+    caplens = torch.tensor([[7], [7], [6], [5], [5], [4], [3], [2]], device=dev)
+    outs = []
+    for opt in (0, 1):
+        SF.set_option("fuse_attn", opt)
+        try:
+            e = enc.clone().requires_grad_(True)
+            p, _, _, a, _ = m(e, tags, caps, caplens)
+            (p.sum() + (a * a).sum()).backward()
+            outs.append((p.detach(), a.detach(), e.grad.clone()))
+        finally:
+            SF.set_option("fuse_attn", 0)
+    for x, y in zip(outs[0], outs[1]):
+        _ok(y, x, 1e-5, "fused vs default")
