@@ -73,7 +73,7 @@ __device__ __forceinline__ void store_tile(float (*lds)[LDS_LD], int tid, const 
 
 // TA: A stored [K][M] (transposed).  TB: B stored [N][K] (transposed).
 template <bool TA, bool TB, bool VEC>
-__global__ __launch_bounds__(256) void sgemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, 3) void sgemm_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float As[2][BK][LDS_LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDS_LD];
 
@@ -225,7 +225,7 @@ int sgemm_ws(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha,
     // split-K when the tile grid alone cannot fill the chip and K is deep enough to amortise the reduce
     const long tiles = (long)cdiv(N, BN) * cdiv(M, BM) * batch;
     int S = 1;
-    if (ws && tiles < 192 && K >= 1024) {
+    if (ws && tiles < 256 && K >= 1024) {
         S = (int)((384 + tiles - 1) / tiles);
         const int smax = K / 512;
         if (S > smax) S = smax;
