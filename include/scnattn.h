@@ -28,8 +28,12 @@ extern "C" {
 int scnattn_version(void);
 const char* scnattn_last_error(void);
 /* Options: "ksplit" (force the split-K factor of the skinny GEMMs; 0 = auto), "profile" (1: bracket
- * the recurrence loops with HIP events on the caller's stream; 2: also every attn_context launch).
- * Returns -1 for an unknown name. */
+ * the recurrence loops with HIP events on the caller's stream; 2: also every attn_context launch),
+ * "chains" (1, default; 2: the recurrence is enqueued as two independent half-batch dependency chains,
+ * chain 0 on the caller's stream and chain 1 on a library-owned side stream by a helper thread,
+ * forked and joined with events so the call stays ordered on the caller's stream; bit-identical, slower),
+ * "fuse_attn" (1: scores+softmax+context in one launch; slower, default 0).
+ * Returns -1 for an unknown name or value. */
 int scnattn_set_option(const char* name, int value);
 /* Sums since the last call: out6 = {forward loop ms, forward steps, backward loop ms, backward steps,
  * attn_context ms, attn_context launches}.  Synchronises on the recorded events. */

@@ -22,6 +22,7 @@ const char* last_error() { return g_err; }
 extern int g_ksplit_scale;
 extern int g_profile;
 extern int g_fuse_attn;
+extern int g_chains;
 int profile_collect(double* out);
 int seq_workspace(const scnattn_dims* d, size_t* saved_bytes, size_t* scratch_bytes);
 int seq_fwd(hipStream_t st, const scnattn_dims* d, const scnattn_params* w, const float* enc, const float* tags,
@@ -49,6 +50,11 @@ int scnattn_set_option(const char* name, int value) {
     }
     if (name && std::strcmp(name, "fuse_attn") == 0) {
         g_fuse_attn = value;
+        return 0;
+    }
+    if (name && std::strcmp(name, "chains") == 0) {
+        if (value != 1 && value != 2) { set_error("scnattn_set_option: chains must be 1 or 2"); return -1; }
+        g_chains = value;
         return 0;
     }
     if (name && std::strcmp(name, "profile") == 0) {

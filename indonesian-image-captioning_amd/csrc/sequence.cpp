@@ -12,6 +12,8 @@
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 #include "../../include/scnattn.h"
 #include "common.h"
@@ -21,6 +23,10 @@ namespace scn {
 
 int g_ksplit_scale = 0;  // 0 = auto; >0 forces ksplit for every skinny launch (tuning/testing)
 int g_profile = 0;       // 1: bracket the recurrence loops with HIP events (scnattn_profile_collect)
+int g_chains = 1;        // 2: the recurrence runs as two independent half-batch chains (rows are independent
+                         //    inside the loop) on two streams fed by two host threads.  Bit-identical, but
+                         //    measured SLOWER (52.8 vs 47.8 us/step): the step kernels are latency-bound, a
+                         //    half-batch launch takes as long as a full one (attn_context 15.1 vs 14.1 us)
 int g_fuse_attn = 0;     // 1: scores+softmax+context+gate as one launch (measured SLOWER: 54.0 vs 47.5 us/step,
                          //    each E-chunk workgroup recomputes all 196 scores through its CU's L2 port)
 
@@ -202,6 +208,72 @@ inline int pick(int rows, int N, int K, int groups) {
 
 }  // namespace
 
+// ---- two-chain execution of a recurrence ---------------------------------------------------------
+// Inside the time loop no kernel mixes batch rows, so rows [0,r0) and [r0,B) are two independent
+// dependency chains.  Chain 0 is enqueued on the caller's stream by the calling thread, chain 1 on a
+// cached non-blocking side stream by a helper thread (one host thread sustains ~3 us per launch, two
+// threads on two streams ~1.5 us aggregate: tools/launch_rate.hip); fork/join are HIP events, so the
+// caller still sees one asynchronous call ordered on its own stream.  Per-row arithmetic does not
+// depend on the split: results are bit-identical to the single-chain order.
+namespace {
+
+constexpr int MAX_DEVICES = 16;
+std::mutex g_side_mu;
+hipStream_t g_side[MAX_DEVICES][2] = {};
+
+int side_stream(int kind, hipStream_t* out) {
+    int dev = 0;
+    SCN_HIP(hipGetDevice(&dev));
+    SCN_ARG(dev >= 0 && dev < MAX_DEVICES, "device index out of range");
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    if (!g_side[dev][kind]) SCN_HIP(hipStreamCreateWithFlags(&g_side[dev][kind], hipStreamNonBlocking));
+    *out = g_side[dev][kind];
+    return 0;
+}
+
+// first row of chain 1: half the batch rounded up to 4 rows so every row offset stays 16-byte aligned
+inline int split_row(int B) {
+    if (g_chains < 2) return B;
+    const int r0 = ((B + 1) / 2 + 3) & ~3;
+    return r0 < B ? r0 : B;
+}
+
+template <class Body>   // body(stream, first_row, max_rows) -> 0 or error code
+int run_chains(hipStream_t st, int kind, int B, Body&& body) {
+    const int r0 = split_row(B);
+    if (r0 >= B) return body(st, 0, B);
+    hipStream_t side = nullptr;
+    SCN_TRY(side_stream(kind, &side));
+    int dev = 0;
+    SCN_HIP(hipGetDevice(&dev));
+    hipEvent_t fork = nullptr, join = nullptr;
+    SCN_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    SCN_HIP(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+    SCN_HIP(hipEventRecord(fork, st));
+    SCN_HIP(hipStreamWaitEvent(side, fork, 0));
+    int rc1 = 0;
+    std::string err1;
+    std::thread helper([&] {
+        if (hipSetDevice(dev) != hipSuccess) { rc1 = -2; err1 = "hipSetDevice failed in chain thread"; return; }
+        rc1 = body(side, r0, B - r0);
+        if (rc1) err1 = last_error();
+    });
+    const int rc0 = body(st, 0, r0);
+    helper.join();
+    // join even after an error so the caller's stream stays ordered after everything that was enqueued
+    const hipError_t e1 = hipEventRecord(join, side);
+    const hipError_t e2 = hipStreamWaitEvent(st, join, 0);
+    (void)hipEventDestroy(fork);
+    (void)hipEventDestroy(join);
+    if (rc0) return rc0;
+    if (rc1) { set_error("%s", err1.c_str()); return rc1; }
+    SCN_HIP(e1);
+    SCN_HIP(e2);
+    return 0;
+}
+
+}  // namespace
+
 int seq_workspace(const scnattn_dims* d, size_t* saved_bytes, size_t* scratch_bytes) {
     SCN_TRY(check_dims(d));
     Saved s;
@@ -262,47 +334,62 @@ int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
     // ---- the recurrence --------------------------------------------------------------------------
     const long BD = (long)B * D;
     hipEvent_t ev0 = prof_begin(st);
-    for (int t = 0; t < T; ++t) {
-        const int bt_ = bt[t];
-        const float* h = s.Hs + t * BD;
-        const float* c = s.Cs + t * BD;
-        const int ksA = pick(bt_, NA, D, 1);
-        SCN_TRY(skinny_gemm(st, bt_, NA, D, 1, h, D, 0, f.WcatA, NA, 0, f.slabA, NA, 0, (long)B * NA, ksA));
-        Slabs pz{nullptr, 0, 0, 0};
-        if (d.has_att) {
-            if (g_fuse_attn && attn_fused_ok(P, E, A, enc, s.att1)) {
-                hipEvent_t evc = g_profile >= 2 ? prof_begin(st) : nullptr;
-                SCN_TRY(attn_fused(st, bt_, P, E, A, enc, s.att1, Slabs{f.slabA, ksA, (long)B * NA, NA},
-                                   w->attention_decoder_att_bias, w->attention_full_att_weight,
-                                   w->attention_full_att_bias, Slabs{f.slabA + A, ksA, (long)B * NA, NA},
-                                   w->f_beta_bias, alphas + (long)t * P, (long)T * P, s.alpha_tm + (long)t * B * P,
-                                   s.att2_all + (long)t * B * A, s.awe_all + (long)t * B * E,
-                                   s.gate_all + (long)t * B * E, s.z_all + (long)t * B * E));
-                prof_end(st, evc, 2, 1);
-            } else {
-                SCN_TRY(attn_scores(st, bt_, P, A, s.att1, Slabs{f.slabA, ksA, (long)B * NA, NA},
-                                    w->attention_decoder_att_bias, w->attention_full_att_weight,
-                                    w->attention_full_att_bias, f.e, s.att2_all + (long)t * B * A));
-                hipEvent_t evc = g_profile >= 2 ? prof_begin(st) : nullptr;   // per-launch timing of the dominant kernel
-                SCN_TRY(attn_context(st, bt_, P, E, enc, f.e, Slabs{f.slabA + A, ksA, (long)B * NA, NA}, w->f_beta_bias,
-                                     alphas + (long)t * P, (long)T * P, s.alpha_tm + (long)t * B * P,
-                                     s.awe_all + (long)t * B * E, s.gate_all + (long)t * B * E, s.z_all + (long)t * B * E));
-                prof_end(st, evc, 2, 1);
+    SCN_TRY(run_chains(st, 0, B, [&](hipStream_t cs, int r0, int rmax) -> int {
+        const float* enc_c = enc + (long)r0 * P * E;
+        const float* att1_c = d.has_att ? s.att1 + (long)r0 * P * A : nullptr;
+        float* slabA = f.slabA + (long)r0 * NA;
+        float* slabC = d.has_att ? f.slabC + (long)r0 * F4 : nullptr;
+        float* slabD = f.slabD + (long)r0 * D;
+        float* e_c = d.has_att ? f.e + (long)r0 * P : nullptr;
+        float* xcat = f.xcat + (long)r0 * 8 * F;
+        const float* qx = s.qx + (long)r0 * F4;
+        const float* qh = s.qh + (long)r0 * F4;
+        for (int t = 0; t < T; ++t) {
+            const int bt_ = (bt[t] - r0 < rmax) ? bt[t] - r0 : rmax;   // rows of this chain still decoding
+            if (bt_ <= 0) break;                                       // bt is non-increasing
+            const long rowT = (long)t * B + r0;                        // first row of this chain in [T][B][.] buffers
+            const float* h = s.Hs + rowT * D;
+            const float* c = s.Cs + rowT * D;
+            const int ksA = pick(bt_, NA, D, 1);
+            SCN_TRY(skinny_gemm(cs, bt_, NA, D, 1, h, D, 0, f.WcatA, NA, 0, slabA, NA, 0, (long)B * NA, ksA));
+            Slabs pz{nullptr, 0, 0, 0};
+            if (d.has_att) {
+                float* alpha_out = alphas + (long)r0 * T * P + (long)t * P;
+                if (g_fuse_attn && attn_fused_ok(P, E, A, enc_c, att1_c)) {
+                    hipEvent_t evc = g_profile >= 2 ? prof_begin(cs) : nullptr;
+                    SCN_TRY(attn_fused(cs, bt_, P, E, A, enc_c, att1_c, Slabs{slabA, ksA, (long)B * NA, NA},
+                                       w->attention_decoder_att_bias, w->attention_full_att_weight,
+                                       w->attention_full_att_bias, Slabs{slabA + A, ksA, (long)B * NA, NA},
+                                       w->f_beta_bias, alpha_out, (long)T * P, s.alpha_tm + rowT * P,
+                                       s.att2_all + rowT * A, s.awe_all + rowT * E, s.gate_all + rowT * E,
+                                       s.z_all + rowT * E));
+                    prof_end(cs, evc, 2, 1);
+                } else {
+                    SCN_TRY(attn_scores(cs, bt_, P, A, att1_c, Slabs{slabA, ksA, (long)B * NA, NA},
+                                        w->attention_decoder_att_bias, w->attention_full_att_weight,
+                                        w->attention_full_att_bias, e_c, s.att2_all + rowT * A));
+                    hipEvent_t evc = g_profile >= 2 ? prof_begin(cs) : nullptr;   // per-launch timing of the dominant kernel
+                    SCN_TRY(attn_context(cs, bt_, P, E, enc_c, e_c, Slabs{slabA + A, ksA, (long)B * NA, NA},
+                                         w->f_beta_bias, alpha_out, (long)T * P, s.alpha_tm + rowT * P,
+                                         s.awe_all + rowT * E, s.gate_all + rowT * E, s.z_all + rowT * E));
+                    prof_end(cs, evc, 2, 1);
+                }
+                const int ksC = pick(bt_, F4, E, 1);
+                SCN_TRY(skinny_gemm(cs, bt_, F4, E, 1, s.z_all + rowT * E, E, 0, w->decode_step_weight_ia + (long)M * F4,
+                                    F4, 0, slabC, F4, 0, (long)B * F4, ksC));
+                pz = Slabs{slabC, ksC, (long)B * F4, F4};
             }
-            const int ksC = pick(bt_, F4, E, 1);
-            SCN_TRY(skinny_gemm(st, bt_, F4, E, 1, s.z_all + (long)t * B * E, E, 0,
-                                w->decode_step_weight_ia + (long)M * F4, F4, 0, f.slabC, F4, 0, (long)B * F4, ksC));
-            pz = Slabs{f.slabC, ksC, (long)B * F4, F4};
+            SCN_TRY(scn_mix_fwd(cs, bt_, F4, pz, s.ex + rowT * F4, Slabs{slabA + colph, ksA, (long)B * NA, NA}, qx, qh,
+                                s.pa_all + rowT * F4, s.ph_all + rowT * F4, xcat));
+            const int ksD = pick(bt_, D, 2 * F, 4);
+            SCN_TRY(skinny_gemm(cs, bt_, D, 2 * F, 4, xcat, 8 * F, 2 * F, f.WD, D, (long)2 * F * D, slabD, D, BD, 4 * BD,
+                                ksD));
+            SCN_TRY(lstm_fwd(cs, bt_, D, Slabs{slabD, ksD, 4 * BD, D}, BD, w->decode_step_bias_ih,
+                             w->decode_step_bias_hh, c, s.gates_all + rowT * 4 * D, s.Cs + (rowT + B) * D,
+                             s.Hs + (rowT + B) * D, s.tanhc_all + rowT * D));
         }
-        SCN_TRY(scn_mix_fwd(st, bt_, F4, pz, s.ex + (long)t * B * F4, Slabs{f.slabA + colph, ksA, (long)B * NA, NA},
-                            s.qx, s.qh, s.pa_all + (long)t * B * F4, s.ph_all + (long)t * B * F4, f.xcat));
-        const int ksD = pick(bt_, D, 2 * F, 4);
-        SCN_TRY(skinny_gemm(st, bt_, D, 2 * F, 4, f.xcat, 8 * F, 2 * F, f.WD, D, (long)2 * F * D, f.slabD, D, BD,
-                            4 * BD, ksD));
-        SCN_TRY(lstm_fwd(st, bt_, D, Slabs{f.slabD, ksD, 4 * BD, D}, BD, w->decode_step_bias_ih, w->decode_step_bias_hh,
-                         c, s.gates_all + (long)t * B * 4 * D, s.Cs + (t + 1) * BD, s.Hs + (t + 1) * BD,
-                         s.tanhc_all + t * BD));
-    }
+        return 0;
+    }));
 
     prof_end(st, ev0, 0, T);
 
@@ -358,40 +445,58 @@ int seq_bwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
     SCN_HIP(hipMemsetAsync(k.dqh_acc, 0, sizeof(float) * B * F4, st));
 
     // ---- reverse recurrence ----------------------------------------------------------------------
-    int ksH = 0;
     hipEvent_t ev0 = prof_begin(st);
-    for (int t = T - 1; t >= 0; --t) {
-        const int bt_ = bt[t];
-        const int btn = (t + 1 < T) ? bt[t + 1] : 0;
-        float* dr = k.dr_all + (long)t * B * 4 * D;
-        float* dcat = k.dcat_all + (long)t * B * NC;
-        float* dpx = k.dpx_all + (long)t * B * F4;
-        SCN_TRY(lstm_bwd(st, bt_, btn, D, k.dhfc_tm + t * BD,
-                         (t + 1 < T) ? Slabs{k.sH, ksH, BD, D} : Slabs{nullptr, 0, 0, 0}, k.dc,
-                         s.gates_all + (long)t * B * 4 * D, s.Cs + t * BD, s.tanhc_all + t * BD, dr));
-        const int ksDb = pick(bt_, 2 * F, D, 4);
-        SCN_TRY(skinny_gemm(st, bt_, 2 * F, D, 4, dr, 4 * D, D, k.WDb, 2 * F, (long)D * 2 * F, k.sDb, 2 * F,
-                            (long)B * 2 * F, (long)4 * B * 2 * F, ksDb));
-        SCN_TRY(scn_mix_bwd(st, bt_, F4, Slabs{k.sDb, ksDb, (long)4 * B * 2 * F, 2 * F}, (long)B * 2 * F, s.qx, s.qh,
-                            s.pa_all + (long)t * B * F4, s.ph_all + (long)t * B * F4, dpx, dcat, NC, k.dqx_acc,
-                            k.dqh_acc));
-        if (d.has_att) {
-            const int ksZ = pick(bt_, E, F4, 1);
-            SCN_TRY(skinny_gemm(st, bt_, E, F4, 1, dpx, F4, 0, k.WaTz, E, 0, k.sZ, E, 0, (long)B * E, ksZ));
-            float* dawe = k.dawe_all + (long)t * B * E;
-            SCN_TRY(gate_bwd(st, bt_, E, Slabs{k.sZ, ksZ, (long)B * E, E}, s.awe_all + (long)t * B * E,
-                             s.gate_all + (long)t * B * E, dawe, dcat + F4, NC));
-            SCN_TRY(attn_dalpha(st, bt_, P, E, enc, dawe, dalphas ? dalphas + (long)t * P : nullptr, (long)T * P,
-                                k.dalpha));
-            SCN_TRY(attn_softmax_bwd(st, bt_, P, A, s.att1, s.att2_all + (long)t * B * A, w->attention_full_att_weight,
-                                     s.alpha_tm + (long)t * B * P, k.dalpha, k.de_all + (long)t * B * P,
-                                     dcat + F4 + E, NC));
+    SCN_TRY(run_chains(st, 1, B, [&](hipStream_t cs, int r0, int rmax) -> int {
+        const float* enc_c = enc + (long)r0 * P * E;
+        const float* att1_c = d.has_att ? s.att1 + (long)r0 * P * A : nullptr;
+        float* sDb = k.sDb + (long)r0 * 2 * F;
+        float* sZ = d.has_att ? k.sZ + (long)r0 * E : nullptr;
+        float* sH = k.sH + (long)r0 * D;
+        float* dalpha = d.has_att ? k.dalpha + (long)r0 * P : nullptr;
+        float* dc = k.dc + (long)r0 * D;
+        const float* qx = s.qx + (long)r0 * F4;
+        const float* qh = s.qh + (long)r0 * F4;
+        float* dqx_acc = k.dqx_acc + (long)r0 * F4;
+        float* dqh_acc = k.dqh_acc + (long)r0 * F4;
+        auto rows_at = [&](int t) { const int n = bt[t] - r0; return n < 0 ? 0 : (n < rmax ? n : rmax); };
+        int ksH = 0, tlast = -1;
+        for (int t = T - 1; t >= 0; --t) {
+            const int bt_ = rows_at(t);
+            if (bt_ <= 0) continue;                                    // this chain starts decoding later (shorter rows)
+            const int btn = (t + 1 < T) ? rows_at(t + 1) : 0;
+            const long rowT = (long)t * B + r0;
+            float* dr = k.dr_all + rowT * 4 * D;
+            float* dcat = k.dcat_all + rowT * NC;
+            float* dpx = k.dpx_all + rowT * F4;
+            SCN_TRY(lstm_bwd(cs, bt_, btn, D, k.dhfc_tm + rowT * D,
+                             btn > 0 ? Slabs{sH, ksH, BD, D} : Slabs{nullptr, 0, 0, 0}, dc, s.gates_all + rowT * 4 * D,
+                             s.Cs + rowT * D, s.tanhc_all + rowT * D, dr));
+            const int ksDb = pick(bt_, 2 * F, D, 4);
+            SCN_TRY(skinny_gemm(cs, bt_, 2 * F, D, 4, dr, 4 * D, D, k.WDb, 2 * F, (long)D * 2 * F, sDb, 2 * F,
+                                (long)B * 2 * F, (long)4 * B * 2 * F, ksDb));
+            SCN_TRY(scn_mix_bwd(cs, bt_, F4, Slabs{sDb, ksDb, (long)4 * B * 2 * F, 2 * F}, (long)B * 2 * F, qx, qh,
+                                s.pa_all + rowT * F4, s.ph_all + rowT * F4, dpx, dcat, NC, dqx_acc, dqh_acc));
+            if (d.has_att) {
+                const int ksZ = pick(bt_, E, F4, 1);
+                SCN_TRY(skinny_gemm(cs, bt_, E, F4, 1, dpx, F4, 0, k.WaTz, E, 0, sZ, E, 0, (long)B * E, ksZ));
+                float* dawe = k.dawe_all + rowT * E;
+                SCN_TRY(gate_bwd(cs, bt_, E, Slabs{sZ, ksZ, (long)B * E, E}, s.awe_all + rowT * E,
+                                 s.gate_all + rowT * E, dawe, dcat + F4, NC));
+                SCN_TRY(attn_dalpha(cs, bt_, P, E, enc_c, dawe,
+                                    dalphas ? dalphas + (long)r0 * T * P + (long)t * P : nullptr, (long)T * P, dalpha));
+                SCN_TRY(attn_softmax_bwd(cs, bt_, P, A, att1_c, s.att2_all + rowT * A, w->attention_full_att_weight,
+                                         s.alpha_tm + rowT * P, dalpha, k.de_all + rowT * P, dcat + F4 + E, NC));
+            }
+            ksH = pick(bt_, D, NC, 1);
+            SCN_TRY(skinny_gemm(cs, bt_, D, NC, 1, dcat, NC, 0, k.WcatT, D, 0, sH, D, 0, BD, ksH));
+            tlast = t;
         }
-        ksH = pick(bt_, D, NC, 1);
-        SCN_TRY(skinny_gemm(st, bt_, D, NC, 1, dcat, NC, 0, k.WcatT, D, 0, k.sH, D, 0, BD, ksH));
-    }
+        // d loss / d h0 for this chain's rows (d/d c0 is k.dc); every row decodes at t = 0
+        SCN_ARG(tlast == 0, "internal: chain without a step at t = 0");
+        SCN_TRY(reduce_slabs(cs, rmax, D, Slabs{sH, ksH, BD, D}, k.dh0 + (long)r0 * D));
+        return 0;
+    }));
     prof_end(st, ev0, 1, T);
-    SCN_TRY(reduce_slabs(st, B, D, Slabs{k.sH, ksH, BD, D}, k.dh0));  // d loss / d h0; d/d c0 is k.dc
 
     // ---- weight gradients: one GEMM per weight over the stacked (t,b) rows ---------------------------
     if (g->decode_step_weight_ia) {

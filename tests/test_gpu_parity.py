@@ -816,3 +816,39 @@ def test_fused_attention_option_matches_default_path(dev):
             SF.set_option("fuse_attn", 0)
     for x, y in zip(outs[0], outs[1]):
         _ok(y, x, 1e-5, "fused vs default")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,lens", [(8, [7, 7, 6, 5, 5, 4, 3, 2]), (13, [9, 9, 9, 8, 8, 7, 6, 5, 5, 3, 2, 2, 1]),
+                                    (32, None), (5, [4, 4, 3, 2, 1]), (4, [3, 3, 2, 2])])
+def test_two_chain_recurrence_is_bit_identical_to_one_chain(dev, B, lens):
+    """Option chains=2 (rows [0,r0) and [r0,B) enqueued as two independent dependency chains on
+    two streams by two host threads) must reproduce the default chains=1 bit for bit: forward outputs, every
+    parameter gradient and d encoder_out.  Covers ragged lengths where chain 1 stops early, a batch
+    whose second chain holds one row, and batches too small to split."""
+    from models.decoders.attention_scn import AttentionSCN
+    from scnattn import functional as SF
+    torch.manual_seed(21)
+    V, L = 60, 10
+    m = AttentionSCN(32, 24, 32, 40, 12, V, encoder_dim=64, dropout=0.0).to(dev).train()
+    enc = torch.rand(B, 4, 4, 64, device=dev)
+    tags = torch.rand(B, 12, device=dev)
+    caps = torch.randint(1, V - 3, (B, L), device=dev)
+    if lens is None:
+        lens = sorted(torch.randint(2, L + 1, (B,)).tolist(), reverse=True)
+    caplens = torch.tensor(lens, device=dev).unsqueeze(1) + 1
+    outs = []
+    for chains in (1, 2):
+        SF.set_option("chains", chains)
+        try:
+            m.zero_grad(set_to_none=True)
+            e = enc.clone().requires_grad_(True)
+            p, _, _, a, _ = m(e, tags, caps, caplens)
+            (p.square().sum() + (a * a).sum()).backward()
+            torch.cuda.synchronize()
+            outs.append([p.detach().clone(), a.detach().clone(), e.grad.clone()] +
+                        [q.grad.clone() for q in m.parameters()])
+        finally:
+            SF.set_option("chains", 1)
+    for i, (x, y) in enumerate(zip(outs[0], outs[1])):
+        assert torch.equal(x, y), "tensor %d differs between chains=1 and chains=2" % i
