@@ -228,3 +228,22 @@ def test_corpus_bleu_known_values():
     assert corpus_bleu([ref], [[9, 9, 9, 9]]) == 0.0
     m = AverageMeter(); m.update(2.0, 3); m.update(4.0, 1)
     assert m.val == 4.0 and m.count == 4 and abs(m.avg - 2.5) < 1e-12
+
+
+def test_corpus_bleu_matches_nltk_golden():
+    """utils.metric.corpus_bleu against values produced by NLTK's corpus_bleu itself (the function the
+    reference calls, trains/attention_scn.py:377); fixture written by oracle/gen_bleu_golden.py.  Where a
+    higher-order precision is 0 NLTK returns ~1e-78 (float_info.min under the log) and we return 0."""
+    import json
+    from utils.metric import corpus_bleu
+    with open(os.path.join(os.path.dirname(__file__), "golden", "bleu_nltk.json")) as fh:
+        gold = json.load(fh)
+    assert len(gold["cases"]) >= 15
+    nonzero = 0
+    for c in gold["cases"]:
+        got4 = corpus_bleu(c["references"], c["hypotheses"])
+        got2 = corpus_bleu(c["references"], c["hypotheses"], weights=(0.5, 0.5))
+        assert abs(got4 - c["bleu4"]) <= 1e-12, (got4, c["bleu4"])
+        assert abs(got2 - c["bleu2"]) <= 1e-12, (got2, c["bleu2"])
+        nonzero += c["bleu4"] > 1e-3
+    assert nonzero >= 6
