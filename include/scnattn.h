@@ -165,6 +165,16 @@ int scnattn_pool_permute_fwd(void* stream, int B, int C, int Hin, int Win, int H
                              long sxb, long sxc, long sxh, long sxw, float* y);
 int scnattn_pool_permute_bwd(void* stream, int B, int C, int Hin, int Win, int Ho, int Wo, const float* dy,
                              float* dx, long sxb, long sxc, long sxh, long sxw);
+/* Input assembly: replaces the per-sample host arithmetic of datasets/caption.py:51-53
+ * (`torch.FloatTensor(imgs[i // cpi] / 255.)` + torchvision Normalize, trains/attention_scn.py:121-126).
+ * src: n_src uint8 images [n_src][C][HW] in HBM (a staged batch or the whole dataset); idx: n_out int64
+ * source rows on the device, or NULL for rows 0..n_out-1; lut: C*256 floats,
+ * lut[c][v] = ((float)(v/255.0) - mean[c]) / std[c] computed by the caller with the reference's own
+ * arithmetic, so the output is bit-identical to the reference's tensor.  dst: [n_out][C][HW]
+ * (channels_last = 0) or [n_out][HW][C] (1), fp32 or bf16 (round-to-nearest-even of the fp32 value).
+ * A row index outside [0, n_src) yields a NaN image instead of a fault. */
+int scnattn_u8_gather_normalize(void* stream, const uint8_t* src, long n_src, const int64_t* idx, long n_out, int C,
+                                long HW, const float* lut, void* dst, int dst_bf16, int channels_last);
 /* Fused BatchNorm2d (+ residual) (+ ReLU) on channels-last maps viewed as [R = N*H*W, C] (C % 4 == 0):
  * the `bn -> relu` / `bn -> (+identity) -> relu` groups of torchvision's Bottleneck behind
  * models/encoders/caption.py:17-22.  `partial` needs scnattn_bn_workspace_floats(C) floats.

@@ -195,6 +195,12 @@ int scnattn_pool_permute_bwd(void* stream, int B, int C, int Hin, int Win, int H
     return pool_permute_bwd(ST(stream), B, C, Hin, Win, Ho, Wo, dy, dx, sxb, sxc, sxh, sxw);
 }
 
+int scnattn_u8_gather_normalize(void* stream, const uint8_t* src, long n_src, const int64_t* idx, long n_out, int C,
+                                long HW, const float* lut, void* dst, int dst_bf16, int channels_last) {
+    return u8_gather_normalize(ST(stream), src, n_src, (const long long*)idx, n_out, C, HW, lut, dst, dst_bf16,
+                               channels_last);
+}
+
 int scnattn_bn_workspace_floats(int C) { return bn_max_chunks() * 2 * C; }
 
 int scnattn_bn_stats(void* stream, int R, int C, const void* x, int bf16, float eps, float momentum, float* partial,

@@ -85,6 +85,9 @@ int hidden_to_bm(hipStream_t st, int B, int T, int D, const int* dl, const float
 int hidden_from_bm(hipStream_t st, int B, int T, int D, const int* dl, const float* dbm,
                    const float* mask_bm, float* out_tm);
 int add_bcast_rows(hipStream_t st, int B, int P, int E, const float* v, float scale, float* x);
+// data.hip: uint8 image rows (gathered by index) -> normalised fp32/bf16 batch, NCHW or channels-last
+int u8_gather_normalize(hipStream_t st, const uint8_t* src, long n_src, const long long* idx, long n_out, int C,
+                        long HW, const float* lut, void* dst, int dst_bf16, int channels_last);
 int pool_permute_fwd(hipStream_t st, int B, int C, int Hin, int Win, int Ho, int Wo, const float* x,
                      long sxb, long sxc, long sxh, long sxw, float* y);
 int pool_permute_bwd(hipStream_t st, int B, int C, int Hin, int Win, int Ho, int Wo, const float* dy,

@@ -1,0 +1,140 @@
+"""GPU tests of the input assembly, through the C ABI: `scnattn_u8_gather_normalize` and
+the device batch loader against the CPU restatement of the reference's per-sample pipeline
+(oracle/data_ref.py) — bit-exact, this is byte/integer work plus a value table."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import data_ref as DR
+from scnattn import data as SD
+from scnattn import h5lite
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden", "hdf5")
+BASE = "tiny_2_cap_per_img_0_min_word_freq"
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from scnattn import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def _ref_batch(u8, rows, mean, std):
+    if mean is None:
+        return torch.stack([DR.image_item(u8[r], None) for r in rows])
+    return torch.stack([DR.image_item(u8[r], mean, std) for r in rows])
+
+
+@pytest.mark.parametrize("shape", [(7, 3, 256, 256), (5, 3, 16, 16), (4, 3, 7, 5), (3, 1, 8, 8), (3, 4, 6, 6)])
+@pytest.mark.parametrize("channels_last", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gather_normalize_bit_exact(dev, shape, channels_last, dtype):
+    rng = np.random.RandomState(sum(shape))
+    u8 = rng.randint(0, 256, size=shape).astype(np.uint8)
+    u8[0, :, 0, :4] = [[0, 1, 254, 255]] * shape[1]
+    C = shape[1]
+    mean = tuple(np.linspace(0.4, 0.5, C)) if C != 3 else DR.MEAN
+    std = tuple(np.linspace(0.2, 0.3, C)) if C != 3 else DR.STD
+    lut = torch.from_numpy(SD.normalize_lut(mean, std)).to(dev)
+    src = torch.from_numpy(u8).to(dev)
+    rows = [shape[0] - 1, 0, 0, 2, 1]
+    idx = torch.tensor(rows, device=dev)
+    got = SD.gather_normalize(src, idx, lut, dtype=dtype, channels_last=channels_last)
+    want = _ref_batch(u8, rows, mean, std).to(dtype)
+    assert got.shape == want.shape and got.dtype == dtype
+    assert got.is_contiguous(memory_format=torch.channels_last if channels_last else torch.contiguous_format)
+    assert torch.equal(got.cpu(), want)
+    got2 = SD.gather_normalize(src, None, lut, n_out=2, dtype=dtype, channels_last=channels_last)   # rows 0..1
+    assert torch.equal(got2.cpu(), _ref_batch(u8, [0, 1], mean, std).to(dtype))
+
+
+def test_gather_normalize_identity_table_and_bad_index(dev):
+    rng = np.random.RandomState(2)
+    u8 = rng.randint(0, 256, size=(3, 3, 32, 32)).astype(np.uint8)
+    src = torch.from_numpy(u8).to(dev)
+    lut = torch.from_numpy(SD.identity_lut(3)).to(dev)
+    got = SD.gather_normalize(src, None, lut)
+    assert torch.equal(got.cpu(), torch.FloatTensor(u8 / 255.))           # transform=None: datasets/caption.py:51
+    bad = SD.gather_normalize(src, torch.tensor([1, 3, -1, 2], device=dev), lut)
+    assert torch.isnan(bad[1]).all() and torch.isnan(bad[2]).all()       # outside the dataset: poisoned, no fault
+    assert torch.equal(bad[0].cpu(), torch.FloatTensor(u8[1] / 255.)) and torch.equal(bad[3], got[2])
+    with pytest.raises(RuntimeError):
+        SD.gather_normalize(src.float(), None, lut)
+    with pytest.raises(RuntimeError):
+        SD.gather_normalize(src, None, lut[:2])
+    with pytest.raises(RuntimeError):
+        SD.gather_normalize(src, None, lut, n_out=4)
+
+
+@pytest.mark.parametrize("split", ["TRAIN", "VAL"])
+@pytest.mark.parametrize("resident", [True, False])
+def test_device_loader_batches_match_reference_items(dev, split, resident):
+    import json
+    with h5lite.File(os.path.join(G, split + "_IMAGES_" + BASE + ".hdf5")) as f:
+        imgs = f["images"][:]
+    caps = json.load(open(os.path.join(G, "%s_CAPTIONS_%s.json" % (split, BASE))))
+    lens = json.load(open(os.path.join(G, "%s_CAPLENS_%s.json" % (split, BASE))))
+    ld = SD.DeviceBatchLoader(G, BASE, split, 4, dev, cpi=2, shuffle=True, seed=3, resident=resident,
+                              channels_last=True)
+    assert ld.resident == resident
+    for epoch in (0, 1):
+        ld.set_epoch(epoch)
+        order = SD.epoch_order(len(caps), epoch, 3, True)
+        seen = 0
+        for b, batch in enumerate(ld):
+            want = DR.caption_batch(imgs, caps, lens, order[b * 4:(b + 1) * 4], 2, split)
+            assert len(batch) == len(want) == (3 if split == "TRAIN" else 4)
+            for got, ref in zip(batch, want):
+                assert got.device.type == "cuda" and got.dtype == ref.dtype and torch.equal(got.cpu(), ref)
+            assert batch[0].is_contiguous(memory_format=torch.channels_last)
+            seen += batch[0].shape[0]
+        assert seen == len(caps) and b + 1 == len(ld)
+
+
+def test_device_loader_full_size_rows_staged_equals_resident_and_ranks_partition(dev, tmp_path):
+    """BASELINE-shaped rows (3x256x256), 96 images written by h5lite.write_arrays: staged and resident
+    modes give identical batches; bf16 output equals the rounded fp32 one; two ranks see disjoint halves of
+    the same permutation; an abandoned iterator shuts its stager thread down."""
+    import json
+    rng = np.random.RandomState(11)
+    N, cpi, L = 96, 5, 12
+    u8 = rng.randint(0, 256, size=(N, 3, 256, 256)).astype(np.uint8)
+    base = "synth_5_cap_per_img_5_min_word_freq"
+    h5lite.write_arrays(str(tmp_path / ("TRAIN_IMAGES_" + base + ".hdf5")), {"images": u8}, {"captions_per_image": cpi})
+    caps = rng.randint(1, 50, size=(N * cpi, L)).tolist()
+    lens = rng.randint(3, L + 1, size=N * cpi).tolist()
+    json.dump(caps, open(str(tmp_path / ("TRAIN_CAPTIONS_" + base + ".json")), "w"))
+    json.dump(lens, open(str(tmp_path / ("TRAIN_CAPLENS_" + base + ".json")), "w"))
+    kw = dict(cpi=cpi, shuffle=True, seed=1)
+    res = SD.DeviceBatchLoader(str(tmp_path), base, "TRAIN", 32, dev, resident=True, **kw)
+    stg = SD.DeviceBatchLoader(str(tmp_path), base, "TRAIN", 32, dev, resident=False, prefetch=2, **kw)
+    b16 = SD.DeviceBatchLoader(str(tmp_path), base, "TRAIN", 32, dev, resident=True, dtype=torch.bfloat16, **kw)
+    order = SD.epoch_order(N * cpi, 0, 1, True)
+    nb = 0
+    for (ia, ca, la), (ib, cb, lb), (ic, _, _) in zip(res, stg, b16):
+        assert torch.equal(ia, ib) and torch.equal(ca, cb) and torch.equal(la, lb)
+        assert torch.equal(ic, ia.to(torch.bfloat16))
+        if nb in (0, 7):
+            rows = order[nb * 32:(nb + 1) * 32]
+            want = DR.caption_batch(u8, caps, lens, rows, cpi, "TRAIN")
+            assert torch.equal(ia.cpu(), want[0]) and torch.equal(ca.cpu(), want[1]) and torch.equal(la.cpu(), want[2])
+        nb += 1
+    assert nb == len(res) == 15
+    r0 = SD.DeviceBatchLoader(str(tmp_path), base, "TRAIN", 32, dev, rank=0, world=2, **kw)
+    r1 = SD.DeviceBatchLoader(str(tmp_path), base, "TRAIN", 32, dev, rank=1, world=2, **kw)
+    assert len(r0) == len(r1) == 8
+    c0 = torch.cat([b[1] for b in r0]).cpu()
+    c1 = torch.cat([b[1] for b in r1]).cpu()
+    allc = torch.tensor(caps)
+    assert torch.equal(c0, allc[order[0::2]]) and torch.equal(c1, allc[order[1::2]])
+    it = iter(stg)
+    next(it)
+    it.close()                                    # generator finaliser stops the stager thread
+    import threading
+    assert not any(t.name == "scnattn-batch-stager" and t.is_alive() for t in threading.enumerate())
