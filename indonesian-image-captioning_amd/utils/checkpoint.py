@@ -1,0 +1,48 @@
+"""Checkpoint files with the reference's layout (utils/checkpoint.py:4-31, :34-61): one `torch.save` of a
+dict holding the *module and optimizer objects themselves* under the keys 'epoch',
+'epochs_since_improvement', 'bleu-4' (or 'accuracy'), 'encoder', 'decoder', 'encoder_optimizer',
+'decoder_optimizer', in 'checkpoint_<model>_<data>.pth.tar' (+ a 'BEST_' copy).  Because this overlay keeps
+the reference's dotted module paths, such a file unpickles to these classes, and `FusedClampAdam`
+(flat parameter/moment buffers) survives the round trip with its parameter views still aliasing the flat
+buffer: torch.save keeps storage sharing inside one file.
+
+`load_checkpoint` is the read side of `trains/attention_scn.py:97-111`: whole-object pickles need
+`weights_only=False`, so only load files you wrote."""
+import os
+
+import torch
+
+
+def save_checkpoint(model_name, data_name, epoch, epochs_since_improvement, encoder, decoder, encoder_optimizer,
+                    decoder_optimizer, bleu4, is_best, folder='.'):
+    state = {'epoch': epoch,
+             'epochs_since_improvement': epochs_since_improvement,
+             'bleu-4': bleu4,
+             'encoder': encoder,
+             'decoder': decoder,
+             'encoder_optimizer': encoder_optimizer,
+             'decoder_optimizer': decoder_optimizer}
+    filename = 'checkpoint_' + model_name + '_' + data_name + '.pth.tar'
+    torch.save(state, os.path.join(folder, filename))
+    # the best checkpoint so far is kept separately so a worse one does not overwrite it
+    if is_best:
+        torch.save(state, os.path.join(folder, 'BEST_' + filename))
+    return os.path.join(folder, filename)
+
+
+def save_tagger_checkpoint(data_name, epoch, epochs_since_improvement, encoder, encoder_optimizer, accuracy, is_best,
+                           folder='.'):
+    state = {'epoch': epoch,
+             'epochs_since_improvement': epochs_since_improvement,
+             'accuracy': accuracy,
+             'encoder': encoder,
+             'encoder_optimizer': encoder_optimizer}
+    filename = 'checkpoint_tagger_' + data_name + '.pth.tar'
+    torch.save(state, os.path.join(folder, filename))
+    if is_best:
+        torch.save(state, os.path.join(folder, 'BEST_' + filename))
+    return os.path.join(folder, filename)
+
+
+def load_checkpoint(path, map_location=None):
+    return torch.load(path, map_location=map_location, weights_only=False)

@@ -247,3 +247,45 @@ def test_corpus_bleu_matches_nltk_golden():
         assert abs(got2 - c["bleu2"]) <= 1e-12, (got2, c["bleu2"])
         nonzero += c["bleu4"] > 1e-3
     assert nonzero >= 6
+
+
+def test_checkpoint_roundtrip_keeps_reference_layout_and_flat_aliasing(tmp_path):
+    """utils/checkpoint.py:4-31: whole modules + optimizers pickled in one dict under the reference's keys
+    and file names; after loading, the fused optimizer's parameters still alias its flat buffer and a
+    `state_dict` feeds utils.loader.load_decoder (utils/loader.py:9-68)."""
+    from models.decoders.attention_scn import AttentionSCN
+    from utils.checkpoint import save_checkpoint, save_tagger_checkpoint, load_checkpoint
+    from utils.loader import load_decoder
+    from utils.optimizer import FusedClampAdam
+    torch.manual_seed(0)
+    dec = AttentionSCN(16, 12, 16, 20, 10, 30, dropout=0.5)      # encoder_dim 2048, as load_decoder assumes
+    opt = FusedClampAdam(dec.parameters(), lr=4e-4, grad_clip=5.0)
+    opt.step_count = 3
+    opt.flat_m.uniform_(-1, 1)
+    enc = torch.nn.Linear(4, 4)
+    path = save_checkpoint("attention_scn", "tiny", 7, 2, enc, dec, None, opt, 0.25, True, folder=str(tmp_path))
+    assert os.path.basename(path) == "checkpoint_attention_scn_tiny.pth.tar"
+    assert os.path.exists(str(tmp_path / "BEST_checkpoint_attention_scn_tiny.pth.tar"))
+    ck = load_checkpoint(path)
+    assert set(ck) == {"epoch", "epochs_since_improvement", "bleu-4", "encoder", "decoder", "encoder_optimizer",
+                       "decoder_optimizer"}
+    assert ck["epoch"] == 7 and ck["epochs_since_improvement"] == 2 and ck["bleu-4"] == 0.25
+    d2, o2 = ck["decoder"], ck["decoder_optimizer"]
+    assert type(d2).__module__ == "models.decoders.attention_scn" and ck["encoder_optimizer"] is None
+    for (k, a), (_, b) in zip(dec.state_dict().items(), d2.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert o2.step_count == 3 and torch.equal(o2.flat_m, opt.flat_m)
+    lo, hi = o2.flat.flat_p.data_ptr(), o2.flat.flat_p.data_ptr() + 4 * o2.flat.flat_p.numel()
+    named = dict(d2.named_parameters())
+    assert all(lo <= p.data_ptr() < hi for p in o2.params)           # views of the flat buffer again
+    assert {id(p) for p in o2.params} == {id(p) for p in named.values() if p.requires_grad}
+    o2.flat.flat_p.zero_()
+    assert all(float(p.detach().abs().max()) == 0.0 for p in d2.parameters())
+    p2 = save_tagger_checkpoint("tiny", 1, 0, enc, None, 0.5, False, folder=str(tmp_path))
+    assert os.path.basename(p2) == "checkpoint_tagger_tiny.pth.tar" and load_checkpoint(p2)["accuracy"] == 0.5
+    assert not os.path.exists(str(tmp_path / "BEST_checkpoint_tagger_tiny.pth.tar"))
+    fresh = load_decoder("attention_scn", dec.state_dict(), 30, embed_dim=12, attention_dim=16, decoder_dim=16,
+                         factored_dim=20, semantic_dim=10)
+    assert torch.equal(fresh.fc.weight.cpu(), dec.fc.weight)
+    with pytest.raises(ValueError, match="model type not found"):
+        load_decoder("nope", {}, 30)
