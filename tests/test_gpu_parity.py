@@ -5,6 +5,8 @@ produced by the reference's own modules.  All calls go through the C ABI (ctypes
 Tolerance: north_star asks for outputs within 1e-4 rel-err of the CPU reference in fp32; we use
 rel_err = max|a-b| / max|b| <= 1e-4 for outputs and <= 2e-4 for gradients (sums over up to 51 steps
 with a different, but fixed, reduction order)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -852,3 +854,43 @@ def test_two_chain_recurrence_is_bit_identical_to_one_chain(dev, B, lens):
             SF.set_option("chains", 1)
     for i, (x, y) in enumerate(zip(outs[0], outs[1])):
         assert torch.equal(x, y), "tensor %d differs between chains=1 and chains=2" % i
+
+
+def test_two_process_data_parallel_decoder_step(dev, tmp_path):
+    """SURVEY 8e cross-check on the HIP path: two processes (gloo collectives, both on this GPU) each run the
+    decoder forward/backward on half of a batch with the bucketed hook-driven all-reduce; their scaled
+    gradient must equal the single-process gradient on the whole batch (fixed-length captions => equal
+    token counts), every bucket must fire during backward, and both ranks must start from rank 0's weights
+    and end the optimizer step with identical parameters."""
+    import socket
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(__file__), "dp_gpu_worker.py")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    env = dict(os.environ)
+    single = subprocess.run([sys.executable, worker, "0", "1", port, str(tmp_path)], env=env, capture_output=True,
+                            text=True, timeout=300)
+    assert single.returncode == 0, single.stderr[-2000:]
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, str(tmp_path)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    for pr in procs:
+        out, err = pr.communicate(timeout=300)
+        assert pr.returncode == 0, err[-2000:]
+    one = torch.load(str(tmp_path / "w1_r0.pt"))
+    r0 = torch.load(str(tmp_path / "w2_r0.pt"))
+    r1 = torch.load(str(tmp_path / "w2_r1.pt"))
+    assert torch.equal(r0["p0"], r1["p0"]), "broadcast did not align the ranks"
+    assert torch.equal(r0["grad"], r1["grad"]) and torch.equal(r0["p1"], r1["p1"])
+    assert r0["buckets"] >= 5 and r0["fired"] == r0["buckets"] == r1["fired"]
+    assert abs(0.5 * (r0["loss"] + r1["loss"]) - one["loss"]) <= 1e-5 * abs(one["loss"])
+    # the single process used seed 77 like rank 0, so its weights are the broadcast ones
+    assert torch.equal(one["p0"], r0["p0"])
+    for name, off, n in zip(one["names"], one["offsets"], one["numels"]):
+        a, b = r0["grad"][off:off + n], one["grad"][off:off + n]
+        if name.endswith("full_att.bias"):
+            assert (a - b).abs().max().item() <= 1e-5
+            continue
+        assert rel_l2(a, b) <= 2e-5, "%s: 2-rank gradient differs from the whole-batch gradient" % name
