@@ -165,6 +165,20 @@ int scnattn_pool_permute_fwd(void* stream, int B, int C, int Hin, int Win, int H
                              long sxb, long sxc, long sxh, long sxw, float* y);
 int scnattn_pool_permute_bwd(void* stream, int B, int C, int Hin, int Win, int Ho, int Wo, const float* dy,
                              float* dx, long sxb, long sxc, long sxh, long sxw);
+/* The loss of the train step, trains/attention_scn.py:222-236, without materialising the packed batch:
+ *   loss = mean over rows (b, t < decode_lengths[b]) of  logsumexp(scores[b,t,:]) - scores[b,t,targets[b,t]]
+ *        + alpha_c * mean over (b,p) of (1 - sum_t alphas[b,t,p])^2            (alphas may be NULL)
+ * scores [B,T,V]; targets int64 with row stride ldt (pass caps_sorted + 1, ldt = L: `targets = caps_sorted[:, 1:]`);
+ * n_tokens = sum_b min(decode_lengths[b], T) (the row count of pack_padded_sequence(...).data).
+ * Workspaces (kept for the backward): row_lse, row_loss [B*T], sm1 [B*P], reg_part [B]; loss [1].
+ * bwd: grad_loss is the DEVICE scalar d/d loss; dscores [B,T,V] is written everywhere (0 for rows that were
+ * not decoded), dalphas [B,T,P] likewise.  A target outside [0,V) makes the loss NaN instead of faulting. */
+int scnattn_caption_loss_fwd(void* stream, int B, int T, int V, int P, const float* scores, const int64_t* targets,
+                             long ldt, const int32_t* decode_lengths, long n_tokens, const float* alphas, float alpha_c,
+                             float* row_lse, float* row_loss, float* sm1, float* reg_part, float* loss);
+int scnattn_caption_loss_bwd(void* stream, int B, int T, int V, int P, const float* scores, const int64_t* targets,
+                             long ldt, const int32_t* decode_lengths, long n_tokens, const float* row_lse,
+                             const float* sm1, float alpha_c, const float* grad_loss, float* dscores, float* dalphas);
 /* Input assembly: replaces the per-sample host arithmetic of datasets/caption.py:51-53
  * (`torch.FloatTensor(imgs[i // cpi] / 255.)` + torchvision Normalize, trains/attention_scn.py:121-126).
  * src: n_src uint8 images [n_src][C][HW] in HBM (a staged batch or the whole dataset); idx: n_out int64

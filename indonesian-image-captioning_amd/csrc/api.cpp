@@ -195,6 +195,20 @@ int scnattn_pool_permute_bwd(void* stream, int B, int C, int Hin, int Win, int H
     return pool_permute_bwd(ST(stream), B, C, Hin, Win, Ho, Wo, dy, dx, sxb, sxc, sxh, sxw);
 }
 
+int scnattn_caption_loss_fwd(void* stream, int B, int T, int V, int P, const float* scores, const int64_t* targets,
+                             long ldt, const int32_t* decode_lengths, long n_tokens, const float* alphas, float alpha_c,
+                             float* row_lse, float* row_loss, float* sm1, float* reg_part, float* loss) {
+    return caption_loss_fwd(ST(stream), B, T, V, P, scores, (const long long*)targets, ldt, decode_lengths, n_tokens,
+                            alphas, alpha_c, row_lse, row_loss, sm1, reg_part, loss);
+}
+
+int scnattn_caption_loss_bwd(void* stream, int B, int T, int V, int P, const float* scores, const int64_t* targets,
+                             long ldt, const int32_t* decode_lengths, long n_tokens, const float* row_lse,
+                             const float* sm1, float alpha_c, const float* grad_loss, float* dscores, float* dalphas) {
+    return caption_loss_bwd(ST(stream), B, T, V, P, scores, (const long long*)targets, ldt, decode_lengths, n_tokens,
+                            row_lse, sm1, alpha_c, grad_loss, dscores, dalphas);
+}
+
 int scnattn_u8_gather_normalize(void* stream, const uint8_t* src, long n_src, const int64_t* idx, long n_out, int C,
                                 long HW, const float* lut, void* dst, int dst_bf16, int channels_last) {
     return u8_gather_normalize(ST(stream), src, n_src, (const long long*)idx, n_out, C, HW, lut, dst, dst_bf16,

@@ -85,6 +85,13 @@ int hidden_to_bm(hipStream_t st, int B, int T, int D, const int* dl, const float
 int hidden_from_bm(hipStream_t st, int B, int T, int D, const int* dl, const float* dbm,
                    const float* mask_bm, float* out_tm);
 int add_bcast_rows(hipStream_t st, int B, int P, int E, const float* v, float scale, float* x);
+// loss.hip: packed cross-entropy + doubly-stochastic attention term of the train step, in place
+int caption_loss_fwd(hipStream_t st, int B, int T, int V, int P, const float* scores, const long long* targets, long ldt,
+                     const int* dl, long n_tokens, const float* alphas, float alpha_c, float* row_lse, float* row_loss,
+                     float* sm1, float* reg_part, float* loss);
+int caption_loss_bwd(hipStream_t st, int B, int T, int V, int P, const float* scores, const long long* targets, long ldt,
+                     const int* dl, long n_tokens, const float* row_lse, const float* sm1, float alpha_c,
+                     const float* gout, float* dscores, float* dalphas);
 // data.hip: uint8 image rows (gathered by index) -> normalised fp32/bf16 batch, NCHW or channels-last
 int u8_gather_normalize(hipStream_t st, const uint8_t* src, long n_src, const long long* idx, long n_out, int C,
                         long HW, const float* lut, void* dst, int dst_bf16, int channels_last);

@@ -68,6 +68,8 @@ _SIGS = {
     "scnattn_mul_bcast": ([vp, i32, i32, i32, vp, vp, vp], i32),
     "scnattn_pool_permute_fwd": ([vp, i32, i32, i32, i32, i32, i32, vp, i64, i64, i64, i64, vp], i32),
     "scnattn_pool_permute_bwd": ([vp, i32, i32, i32, i32, i32, i32, vp, vp, i64, i64, i64, i64], i32),
+    "scnattn_caption_loss_fwd": ([vp, i32, i32, i32, i32, vp, vp, i64, vp, i64, vp, f32, vp, vp, vp, vp, vp], i32),
+    "scnattn_caption_loss_bwd": ([vp, i32, i32, i32, i32, vp, vp, i64, vp, i64, vp, vp, f32, vp, vp, vp], i32),
     "scnattn_u8_gather_normalize": ([vp, vp, i64, vp, i64, i32, i64, vp, vp, i32, i32], i32),
     "scnattn_bn_workspace_floats": ([i32], i32),
     "scnattn_bn_stats": ([vp, i32, i32, vp, i32, f32, f32, vp, vp, vp, vp, vp], i32),

@@ -467,6 +467,67 @@ def bn_act(z, res, gamma, beta, run_mean, run_var, training, momentum, eps, relu
 
 
 # ----------------------------------------------------------------------------------------------
+# The train step's loss (trains/attention_scn.py:222-236) on the unpacked (B, T, V) scores
+# ----------------------------------------------------------------------------------------------
+class _CaptionLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scores, alphas, caps_sorted, dl_dev, n_tokens, alpha_c):
+        require_cuda(scores, alphas, caps_sorted, dl_dev)
+        scores = f32c(scores)
+        alphas = None if alphas is None else f32c(alphas)
+        B, T, V = scores.shape
+        P = alphas.shape[2] if alphas is not None else 0
+        if caps_sorted.dtype != torch.int64 or caps_sorted.dim() != 2 or caps_sorted.stride(1) != 1 \
+                or caps_sorted.shape[0] != B or caps_sorted.shape[1] < T + 1:
+            raise RuntimeError("caption_loss: caps_sorted must be int64 (B, >= T+1) with unit column stride")
+        if dl_dev.dtype != torch.int32 or dl_dev.numel() != B or not dl_dev.is_contiguous():
+            raise RuntimeError("caption_loss: decode lengths must be a contiguous int32 vector of B entries")
+        if alphas is not None and tuple(alphas.shape[:2]) != (B, T):
+            raise RuntimeError("caption_loss: alphas must be (B, T, P)")
+        dev = scores.device
+        ws = torch.empty(2 * B * T + B * P + B + 1, device=dev, dtype=torch.float32)
+        row_lse, row_loss = ws[:B * T], ws[B * T:2 * B * T]
+        sm1, reg_part = ws[2 * B * T:2 * B * T + B * P], ws[2 * B * T + B * P:2 * B * T + B * P + B]
+        loss = ws[-1:]
+        tgt = C.c_void_p(caps_sorted.data_ptr() + 8)            # targets = caps_sorted[:, 1:]
+        call("scnattn_caption_loss_fwd", stream_of(scores), B, T, V, P, ptr(scores), tgt, caps_sorted.stride(0),
+             ptr(dl_dev), int(n_tokens), ptr(alphas), float(alpha_c), ptr(row_lse), ptr(row_loss),
+             ptr(sm1) if P else None, ptr(reg_part) if P else None, ptr(loss))
+        ctx.save_for_backward(scores, caps_sorted, dl_dev, ws)
+        ctx.meta = (B, T, V, P, int(n_tokens), float(alpha_c), alphas is not None)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        scores, caps_sorted, dl_dev, ws = ctx.saved_tensors
+        B, T, V, P, n_tokens, alpha_c, has_alpha = ctx.meta
+        g = f32c(g).reshape(1)
+        dscores = torch.empty_like(scores) if ctx.needs_input_grad[0] else None
+        dalphas = torch.empty((B, T, P), device=scores.device, dtype=torch.float32) \
+            if (has_alpha and ctx.needs_input_grad[1]) else None
+        if dscores is None:                                       # the kernel pair always produces d scores
+            dscores = torch.empty_like(scores)
+        row_lse = ws[:B * T]
+        sm1 = ws[2 * B * T:2 * B * T + B * P]
+        call("scnattn_caption_loss_bwd", stream_of(scores), B, T, V, P, ptr(scores),
+             C.c_void_p(caps_sorted.data_ptr() + 8), caps_sorted.stride(0), ptr(dl_dev), n_tokens, ptr(row_lse),
+             ptr(sm1) if dalphas is not None else None, alpha_c, ptr(g), ptr(dscores), ptr(dalphas))
+        return (dscores if ctx.needs_input_grad[0] else None), dalphas, None, None, None, None
+
+
+def caption_loss(scores, caps_sorted, decode_lengths, alphas=None, alpha_c=1.0, dl_dev=None):
+    """`CrossEntropyLoss()(pack(scores), pack(caps_sorted[:, 1:])) + alpha_c * ((1 - alphas.sum(1))**2).mean()`
+    of trains/attention_scn.py:222-236 without building the packed batch.  scores (B, T, V) and alphas
+    (B, T, P) as the decoder returns them, decode_lengths the decoder's list; dl_dev optionally the same
+    lengths as an int32 device vector (saves one small host-to-device copy)."""
+    T = scores.shape[1]
+    n_tokens = sum(min(int(l), T) for l in decode_lengths)
+    if dl_dev is None:
+        dl_dev = torch.tensor(list(decode_lengths), dtype=torch.int32, device=scores.device)
+    return _CaptionLoss.apply(scores, alphas, caps_sorted, dl_dev, n_tokens, alpha_c)
+
+
+# ----------------------------------------------------------------------------------------------
 def clamp_adam_(p, g, m, v, lr, step, clip, beta1=0.9, beta2=0.999, eps=1e-8, gscale=1.0):
     """Fused clamp(+-clip) + Adam on flat fp32 buffers (utils/optimizer.py:1-11 + torch.optim.Adam)."""
     require_cuda(p, g, m, v)

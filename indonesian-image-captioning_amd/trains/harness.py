@@ -16,6 +16,7 @@ from models.decoders.pure_scn import PureSCN
 from models.decoders.pure_attention import PureAttention
 from models.encoders.caption import EncoderCaption
 from models.encoders.tagger import EncoderTagger
+from scnattn import functional as SF
 from scnattn.dp import GradReducer, broadcast_parameters
 from utils.optimizer import FusedClampAdam
 
@@ -59,10 +60,11 @@ def build_decoder(kind, cfg):
 class TrainStep:
     def __init__(self, kind="attention_scn", fine_tune_encoder=True, device="cuda", seed=1234, encoder=True,
                  bucket_mb=32, graph_encoder=False, tagger=False, force_reduce=False, encoder_dtype="f32",
-                 **overrides):
+                 fused_loss=True, **overrides):
         self.cfg = dict(DEFAULTS)
         self.cfg.update(overrides)
         self.kind = kind
+        self.fused_loss = fused_loss
         # "bf16": the ResNet trunk runs under bf16 autocast (MIOpen bf16 MFMA convolutions, bf16 feature maps
         # through the fused BatchNorm kernels, fp32 master weights/statistics); the decoder stays fp32.
         # This is BASELINE config 5's mixed-precision flavour, NOT the headline fp32 metric.
@@ -113,7 +115,11 @@ class TrainStep:
                 sample = torch.randn(cfg["batch_size"], 3, cfg["image_size"], cfg["image_size"], device=self.device)
                 self.encoder_call = torch.cuda.make_graphed_callables(self.encoder, (sample,), num_warmup_iters=3)
 
-    def loss_fn(self, scores, caps_sorted, decode_lengths, alphas):
+    def loss_fn(self, scores, caps_sorted, decode_lengths, alphas, dl_dev=None):
+        """trains/attention_scn.py:222-236.  On the GPU: one fused forward/backward pair on the unpacked
+        scores (csrc/loss.hip); `fused_loss=False` keeps the reference's op sequence (tests compare the two)."""
+        if self.fused_loss and scores.is_cuda:
+            return SF.caption_loss(scores, caps_sorted, decode_lengths, alphas, self.cfg["alpha_c"], dl_dev)
         targets = caps_sorted[:, 1:]
         scores = pack_padded_sequence(scores, decode_lengths, batch_first=True).data
         targets = pack_padded_sequence(targets, decode_lengths, batch_first=True).data
@@ -131,13 +137,14 @@ class TrainStep:
         if self.tagger is not None:
             tags = tags.float()
         if self.kind == "attention_scn":
-            scores, caps_sorted, decode_lengths, alphas, _ = self.decoder(encoder_out, tags, caps, caplens)
+            scores, caps_sorted, decode_lengths, alphas, sort_ind = self.decoder(encoder_out, tags, caps, caplens)
         elif self.kind == "pure_scn":
-            scores, caps_sorted, decode_lengths, _ = self.decoder(encoder_out, tags, caps, caplens)
+            scores, caps_sorted, decode_lengths, sort_ind = self.decoder(encoder_out, tags, caps, caplens)
             alphas = None
         else:
-            scores, caps_sorted, decode_lengths, alphas, _ = self.decoder(encoder_out, caps, caplens)
-        loss = self.loss_fn(scores, caps_sorted, decode_lengths, alphas)
+            scores, caps_sorted, decode_lengths, alphas, sort_ind = self.decoder(encoder_out, caps, caplens)
+        dl_dev = (caplens.reshape(-1)[sort_ind] - 1).to(torch.int32) if self.fused_loss else None
+        loss = self.loss_fn(scores, caps_sorted, decode_lengths, alphas, dl_dev)
         self.decoder_optimizer.zero_grad()
         if self.encoder_optimizer is not None:
             self.encoder_optimizer.zero_grad()

@@ -894,3 +894,70 @@ def test_two_process_data_parallel_decoder_step(dev, tmp_path):
             assert (a - b).abs().max().item() <= 1e-5
             continue
         assert rel_l2(a, b) <= 2e-5, "%s: 2-rank gradient differs from the whole-batch gradient" % name
+
+
+@pytest.mark.parametrize("B,T,V,P,lens,with_alpha", [
+    (6, 5, 40, 9, [5, 5, 4, 3, 3, 1], True),        # ragged, V % 4 == 0
+    (4, 7, 37, 16, [7, 6, 2, 1], True),             # V % 4 != 0: scalar path
+    (5, 4, 1000, 0, [4, 4, 4, 4, 4], False),        # PureSCN: no alphas; full lengths
+    (3, 6, 10000, 196, [6, 4, 3], True),            # BASELINE vocabulary / pixel count
+])
+def test_fused_caption_loss_matches_oracle(dev, B, T, V, P, lens, with_alpha):
+    """csrc/loss.hip against the oracle's restatement of trains/attention_scn.py:222-236
+    (pack_padded_sequence x2, CrossEntropyLoss, doubly-stochastic term): value, d scores, d alphas; rows that
+    were not decoded get exactly zero gradient; the loss is scaled by an upstream factor to exercise g."""
+    from oracle import scnattn_ref as R
+    from scnattn import functional as SF
+    g = torch.Generator().manual_seed(B * 100 + V)
+    scores = (3 * torch.randn(B, T, V, generator=g)).requires_grad_(True)
+    caps = torch.randint(0, V, (B, T + 2), generator=g)
+    alphas = None
+    if with_alpha:
+        alphas = torch.softmax(torch.randn(B, T, P, generator=g), dim=2)
+        for b, l in enumerate(lens):
+            alphas[b, l:] = 0                      # the decoder leaves rows beyond decode_length at zero
+        alphas.requires_grad_(True)
+    ref, _, _ = R.caption_loss(scores, caps, lens, alphas, alpha_c=0.7)
+    (2.5 * ref).backward()
+    sd = scores.detach().to(dev).requires_grad_(True)
+    ad = alphas.detach().to(dev).requires_grad_(True) if with_alpha else None
+    got = SF.caption_loss(sd, caps.to(dev), lens, ad, alpha_c=0.7)
+    assert got.dim() == 0
+    (2.5 * got).backward()
+    assert abs(got.item() - ref.item()) <= 1e-5 * abs(ref.item())
+    _ok(sd.grad, scores.grad, 1e-5, "d scores")
+    for b, l in enumerate(lens):
+        assert float(sd.grad[b, l:].abs().max()) == 0.0 if l < T else True
+        assert float(sd.grad[b, :l].sum(dim=1).abs().max()) <= 1e-6          # softmax - onehot sums to 0 per row
+    if with_alpha:
+        _ok(ad.grad, alphas.grad, 1e-5, "d alphas")
+    dl_dev = torch.tensor(lens, dtype=torch.int32, device=dev)
+    again = SF.caption_loss(sd.detach(), caps.to(dev), lens, None if ad is None else ad.detach(), 0.7, dl_dev)
+    assert torch.equal(again, got.detach())                                    # deterministic, dl_dev path identical
+    bad = caps.clone()
+    bad[0, 1] = V + 5
+    assert torch.isnan(SF.caption_loss(sd.detach(), bad.to(dev), lens, None, 0.7))   # bad label: NaN, no fault
+    with pytest.raises(RuntimeError):
+        SF.caption_loss(sd.detach().cpu(), caps, lens)
+
+
+def test_train_step_fused_loss_equals_reference_op_sequence(dev):
+    """Whole decoder train step at BASELINE dims (B=32, T=51, V=10000), once with the fused loss and once
+    with the reference's op sequence (pack_padded_sequence + CrossEntropyLoss + alpha term in torch ops):
+    same loss and the same parameters after the update (dropout off, identical seeds)."""
+    from trains.harness import TrainStep, synthetic_batch
+    outs = []
+    for fused in (True, False):
+        ts = TrainStep(kind="attention_scn", fine_tune_encoder=False, device=dev, encoder=False, dropout=0.0,
+                       fused_loss=fused, seed=4)
+        cfg = ts.cfg
+        _, tags, caps, caplens = synthetic_batch(32, cfg["vocab_size"], cfg["max_len"], 8, cfg["semantic_dim"], dev, 6,
+                                                 ragged=True)
+        enc = torch.rand(32, 14, 14, 2048, generator=torch.Generator().manual_seed(8)).to(dev)
+        loss = ts.step(None, tags, caps, caplens, enc)
+        ts.decoder_optimizer.flat.gather()
+        outs.append((loss.item(), ts.decoder_optimizer.flat.flat_g.clone(), ts.decoder_optimizer.flat.flat_p.clone()))
+        del ts
+    assert abs(outs[0][0] - outs[1][0]) <= 2e-6 * abs(outs[1][0])
+    assert rel_l2(outs[0][1], outs[1][1]) <= 1e-5
+    assert rel_l2(outs[0][2], outs[1][2]) <= 1e-5
