@@ -19,10 +19,15 @@ def sort_by_length(encoder_out, encoded_captions, caption_lengths, sort_ind=None
         lens, sort_ind = lens.sort(dim=0, descending=True, stable=True)
     else:
         lens = lens[sort_ind]
-    enc = enc[sort_ind]
-    caps = encoded_captions[sort_ind]
-    decode_lengths = (lens - 1).tolist()  # the one host sync of the forward pass, as in the reference
-    return enc, caps, decode_lengths, (lens - 1).to(torch.int32), sort_ind
+    # the one host sync of the forward pass, as in the reference (`.tolist()`, :131); the permutation rides
+    # along so that a batch that is already in order (fixed-length captions, or a loader that sorts) skips
+    # the 51 MB gather of encoder_out and, when the encoder is fine-tuned, its scatter in the backward pass
+    host = torch.stack([lens - 1, sort_ind]).tolist()
+    decode_lengths, perm = host
+    if perm != list(range(B)):
+        enc = enc[sort_ind]
+        encoded_captions = encoded_captions[sort_ind]
+    return enc, encoded_captions, decode_lengths, (lens - 1).to(torch.int32), sort_ind
 
 
 def active_rows(decode_lengths):

@@ -62,6 +62,18 @@ def _params_struct(tensors):
     return p
 
 
+_POISON = False     # tests: NaN-fill workspaces that are claimed to be fully overwritten
+
+
+def _workspace(nfloats, dev, fully_written):
+    if not fully_written:
+        return torch.zeros(nfloats, device=dev, dtype=torch.float32)
+    ws = torch.empty(nfloats, device=dev, dtype=torch.float32)
+    if _POISON:
+        ws.fill_(float("nan"))
+    return ws
+
+
 class _DecoderSeq(torch.autograd.Function):
     @staticmethod
     def forward(ctx, meta, enc, tags, caps, dl_dev, drop_mask, *weights):
@@ -75,10 +87,15 @@ class _DecoderSeq(torch.autograd.Function):
         drop_mask = f32c(drop_mask)
         sv, sc = C.c_size_t(), C.c_size_t()
         call("scnattn_seq_workspace", C.byref(d), C.byref(sv), C.byref(sc))
-        saved = torch.zeros(sv.value // 4, device=dev, dtype=torch.float32)
+        # Rows (t, b >= b_t) of the time-major buffers are never written by the kernels but are read by the
+        # post-loop GEMMs (and returned, for alphas), so they must be zero -- unless every row decodes at every
+        # step (fixed-length captions), where each element is written before it is read and the 120 MB fill is
+        # skipped.  `_POISON` (tests) fills with NaN instead to prove exactly that.
+        full = min(bt_host) == d.B
+        saved = _workspace(sv.value // 4, dev, full)
         scratch = torch.empty(sc.value // 4, device=dev, dtype=torch.float32)
         preds = torch.empty((d.B, d.T, d.V), device=dev, dtype=torch.float32)
-        alphas = torch.zeros((d.B, d.T, d.P), device=dev, dtype=torch.float32) if d.has_att else None
+        alphas = _workspace(d.B * d.T * d.P, dev, full).view(d.B, d.T, d.P) if d.has_att else None
         bt = (C.c_int32 * d.T)(*bt_host)
         w = _params_struct(weights)
         call("scnattn_seq_fwd", stream_of(enc), C.byref(d), C.byref(w), ptr(enc), ptr(tags), ptr(caps), ptr(dl_dev),
@@ -101,7 +118,7 @@ class _DecoderSeq(torch.autograd.Function):
         dev = enc.device
         dpreds = f32c(dpreds)
         dalphas = f32c(dalphas) if (d.has_att and dalphas is not None) else None
-        scratch = torch.zeros(scratch_bytes // 4, device=dev, dtype=torch.float32)
+        scratch = _workspace(scratch_bytes // 4, dev, min(bt_host) == d.B)
         need = ctx.needs_input_grad  # (meta, enc, tags, caps, dl, mask, *weights)
         grads = []
         for i, (name, wt) in enumerate(zip(PARAM_FIELDS, weights)):

@@ -961,3 +961,45 @@ def test_train_step_fused_loss_equals_reference_op_sequence(dev):
     assert abs(outs[0][0] - outs[1][0]) <= 2e-6 * abs(outs[1][0])
     assert rel_l2(outs[0][1], outs[1][1]) <= 1e-5
     assert rel_l2(outs[0][2], outs[1][2]) <= 1e-5
+
+
+@pytest.mark.parametrize("kind", ["attention_scn", "pure_scn"])
+def test_full_length_batch_never_reads_unwritten_workspace(dev, kind):
+    """With fixed-length captions the 120 MB zero fills of the sequence workspaces are skipped because every
+    element is written before it is read.  Proof: NaN-poison those workspaces; outputs and every gradient must
+    stay finite and bit-identical to the unpoisoned run.  Also covers the skipped identity permutation (the
+    batch is already in length order) against an explicitly permuted run."""
+    from models.decoders.attention_scn import AttentionSCN
+    from models.decoders.pure_scn import PureSCN
+    from scnattn import functional as SF
+    torch.manual_seed(31)
+    B, V, L = 8, 50, 9
+    if kind == "attention_scn":
+        m = AttentionSCN(32, 24, 32, 40, 12, V, encoder_dim=64, dropout=0.0).to(dev).train()
+    else:
+        m = PureSCN(24, 32, 40, 12, V, encoder_dim=64, dropout=0.0).to(dev).train()
+    enc = torch.rand(B, 4, 4, 64, device=dev)
+    tags = torch.rand(B, 12, device=dev)
+    caps = torch.randint(1, V - 3, (B, L), device=dev)
+    caplens = torch.full((B, 1), L, device=dev)
+    runs = []
+    for poison in (False, True):
+        SF._POISON = poison
+        try:
+            m.zero_grad(set_to_none=True)
+            e = enc.clone().requires_grad_(True)
+            out = m(e, tags, caps, caplens)
+            loss = out[0].square().sum() + (out[3].square().sum() if kind == "attention_scn" else 0)
+            loss.backward()
+            runs.append([out[0].detach().clone(), e.grad.clone()] + [p.grad.clone() for p in m.parameters()] +
+                        ([out[3].detach().clone()] if kind == "attention_scn" else []))
+        finally:
+            SF._POISON = False
+    for a, b in zip(*runs):
+        assert torch.isfinite(b).all() and torch.equal(a, b)
+    # identity permutation skipped == explicit permutation applied: reverse the batch and un-reverse the results
+    rev = torch.arange(B - 1, -1, -1, device=dev)
+    e2 = enc[rev].clone().requires_grad_(True)
+    out2 = m(e2, tags, caps[rev], caplens, sort_ind=rev)           # Q1: tags are indexed un-permuted by sorted position
+    assert torch.equal(out2[1], caps) and out2[-1] is rev
+    _ok(out2[0], runs[0][0], 1e-6, "predictions under an explicit permutation")
