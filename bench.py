@@ -170,6 +170,7 @@ def main():
                          "*_IMAGES_*.hdf5 + JSON captions written to a temp dir) through scnattn.data.DeviceBatchLoader "
                          "inside the timed region; resident = uint8 dataset in HBM, staged = pinned uint8 batches over PCIe")
     ap.add_argument("--data-images", type=int, default=1024, help="images in the synthetic HDF5 file")
+    ap.add_argument("--gemm-opts", default="", help="diagnostics: target,kmin,kmin_small of the split-K policy")
     ap.add_argument("--graph", action="store_true", help="replay the encoder as HIP graphs (measured slower)")
     args = ap.parse_args()
 
@@ -195,6 +196,9 @@ def main():
     if args.ksplit:
         SF.set_option("ksplit", args.ksplit)
     SF.set_option("chains", args.chains)
+    if args.gemm_opts:
+        for name, v in zip(("gemm_target", "gemm_kmin", "gemm_kmin_small", "gemm_gate"), args.gemm_opts.split(",")):
+            SF.set_option(name, int(v))
     fine_tune = not args.no_finetune
     # MIOpen JIT-compiles its convolution kernels on first use (this image has no gfx950 kernel database)
     # and caches the binaries per user.  With N ranks starting together every rank would compile the same

@@ -76,6 +76,7 @@ int gate_bwd(hipStream_t st, int rows, int E, Slabs dz, const float* awe, const 
 int transpose2d(hipStream_t st, int R, int C, const float* in, long ldi, float* out, long ldo);
 int copy2d(hipStream_t st, int R, int C, const float* in, long ldi, float* out, long ldo);
 int colsum(hipStream_t st, int R, int N, const float* X, long ld, float* out, float beta);
+int colsum_masked(hipStream_t st, int R, int N, const float* X, long ld, const float* rowmask, float* out, float beta);
 int gather_rows_tm(hipStream_t st, int B, int T, int L, int M, const long long* caps, const float* table,
                    int V, float* out_tm);
 int scatter_add_rows_tm(hipStream_t st, int B, int T, int L, int M, const long long* caps, const int* dl,

@@ -38,8 +38,10 @@ __global__ __launch_bounds__(256) void copy2d_kernel(int R, int C, const float* 
 
 // out[n] = beta*out[n] + sum_r X[r][n]; one workgroup per 16 columns x 16 row lanes, 4 independent
 // loads in flight per thread, fixed summation order (deterministic).
+template <bool MASK>
 __global__ __launch_bounds__(256) void colsum_kernel(int R, int N, const float* __restrict__ X, long ld,
-                                                     float* __restrict__ out, float beta) {
+                                                     const float* __restrict__ rowmask, float* __restrict__ out,
+                                                     float beta) {
     __shared__ float part[16][17];
     const int c = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int n = blockIdx.x * 16 + c;
@@ -47,11 +49,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(int R, int N, const float* 
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int r = rl;
     for (; r + 48 < R; r += 64) {
-        const float a0 = X[(long)r * ld + nc], a1 = X[(long)(r + 16) * ld + nc];
-        const float a2 = X[(long)(r + 32) * ld + nc], a3 = X[(long)(r + 48) * ld + nc];
+        float a0 = X[(long)r * ld + nc], a1 = X[(long)(r + 16) * ld + nc];
+        float a2 = X[(long)(r + 32) * ld + nc], a3 = X[(long)(r + 48) * ld + nc];
+        if (MASK) {      // rows with mask 0 do not contribute whatever they hold (select, not multiply)
+            a0 = rowmask[r] != 0.f ? a0 : 0.f;
+            a1 = rowmask[r + 16] != 0.f ? a1 : 0.f;
+            a2 = rowmask[r + 32] != 0.f ? a2 : 0.f;
+            a3 = rowmask[r + 48] != 0.f ? a3 : 0.f;
+        }
         s0 += a0; s1 += a1; s2 += a2; s3 += a3;
     }
-    for (; r < R; r += 16) s0 += X[(long)r * ld + nc];
+    for (; r < R; r += 16) {
+        const float a = X[(long)r * ld + nc];
+        s0 += (!MASK || rowmask[r] != 0.f) ? a : 0.f;
+    }
     part[rl][c] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (rl == 0 && n < N) {
@@ -298,7 +309,16 @@ int copy2d(hipStream_t st, int R, int C, const float* in, long ldi, float* out, 
 int colsum(hipStream_t st, int R, int N, const float* X, long ld, float* out, float beta) {
     if (N <= 0) return 0;
     SCN_ARG(X && out && R >= 0, "colsum: bad argument");
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 16)), dim3(256), 0, st, R, N, X, ld, out, beta);
+    hipLaunchKernelGGL(colsum_kernel<false>, dim3(cdiv(N, 16)), dim3(256), 0, st, R, N, X, ld, nullptr, out, beta);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
+// out[n] = beta*out[n] + sum over rows with rowmask[r] != 0 of X[r][n]
+int colsum_masked(hipStream_t st, int R, int N, const float* X, long ld, const float* rowmask, float* out, float beta) {
+    if (N <= 0) return 0;
+    SCN_ARG(X && out && rowmask && R >= 0, "colsum_masked: bad argument");
+    hipLaunchKernelGGL(colsum_kernel<true>, dim3(cdiv(N, 16)), dim3(256), 0, st, R, N, X, ld, rowmask, out, beta);
     SCN_LAUNCH_CHECK();
     return 0;
 }

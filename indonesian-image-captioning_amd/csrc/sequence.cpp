@@ -424,8 +424,7 @@ int seq_bwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
         SCN_TRY(sgemm_ws(st, true, false, V, D, B * T, 1.f, dpreds, V, s.Hd_bm, D, 0.f, g->fc_weight, D, nullptr, nullptr,
                       1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
     if (g->fc_bias)  // only rows that were decoded carry the bias
-        SCN_TRY(sgemm_ws(st, false, false, 1, V, B * T, 1.f, s.rowmask, B * T, dpreds, V, 0.f, g->fc_bias, V, nullptr,
-                      nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
+        SCN_TRY(colsum_masked(st, B * T, V, dpreds, V, s.rowmask, g->fc_bias, 0.f));
     SCN_TRY(hidden_from_bm(st, B, T, D, dl_dev, k.dHd_bm, drop_mask, k.dhfc_tm));
 
     // ---- transposed weight layouts for the backward contractions ------------------------------------

@@ -210,6 +210,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
 
 }  // namespace
 
+// split-K policy knobs (scnattn_set_option "gemm_target" / "gemm_kmin" / "gemm_kmin_small")
+int g_gemm_gate = 256;        // split only when the tile grid alone has fewer workgroups than this
+int g_gemm_target = 512;      // aim for this many workgroups (tiles x splits)
+int g_gemm_kmin = 256;        // at least this much K per split ...
+int g_gemm_kmin_small = 128;  // ... or this much when the product has <= 16 tiles (32-row operands)
+
 int sgemm_ws(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, const float* A, long lda,
              const float* B, long ldb, float beta, float* C, long ldc, const float* bias, const float* rowmask,
              int batch, long sA, long sB, long sC, float* ws, long ws_floats) {
@@ -223,11 +229,14 @@ int sgemm_ws(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha,
     }
     SCN_ARG(beta == 0.f || ((long)(M - 1) * ldc + N) * 4 < 0x7fffffffL, "sgemm: C too large for beta != 0");
     // split-K when the tile grid alone cannot fill the chip and K is deep enough to amortise the reduce
+    // (measured on the decoder's shapes: one 128x128 tile per CU leaves the MFMA pipe ~45 % idle, and a
+    //  32-row product with 16 tiles ran 85 us un-split)
     const long tiles = (long)cdiv(N, BN) * cdiv(M, BM) * batch;
     int S = 1;
-    if (ws && tiles < 256 && K >= 1024) {
-        S = (int)((384 + tiles - 1) / tiles);
-        const int smax = K / 512;
+    const int kmin = tiles <= 16 ? g_gemm_kmin_small : g_gemm_kmin;
+    if (ws && tiles < g_gemm_gate && K >= 2 * kmin) {
+        S = (int)((g_gemm_target + tiles - 1) / tiles);
+        const int smax = K / kmin;
         if (S > smax) S = smax;
         if (S > SCN_MAX_KSPLIT) S = SCN_MAX_KSPLIT;
         while (S > 1 && (long)S * batch * M * N > ws_floats) --S;

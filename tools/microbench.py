@@ -110,6 +110,14 @@ gemm("dWe", 512, 2048, 6272, ta=True)
 gemm("denc", 6272, 2048, 512)
 gemm("dWa", 2048, 2048, 1632, ta=True)
 gemm("ex", 1632, 2048, 512)
+gemm("dWaM", 512, 2048, 1632, ta=True)
+gemm("dHa", 512, 2048, 1632, ta=True)
+gemm("dWbeta", 2048, 512, 1632, ta=True)
+gemm("dWd", 512, 512, 1632, ta=True)
+gemm("demb", 1632, 512, 2048, tb=True)
+gemm("dWc_g", 512, 512, 1632, ta=True)
+gemm("init_h", 32, 512, 2048, tb=True)
+gemm("qx", 32, 2048, 1000)
 gemm("sq4096", 4096, 4096, 4096)
 gemm("sq4096", 4096, 4096, 4096, tb=True)
 gemm("sq4096", 4096, 4096, 4096, ta=True)
