@@ -170,6 +170,7 @@ def main():
                          "*_IMAGES_*.hdf5 + JSON captions written to a temp dir) through scnattn.data.DeviceBatchLoader "
                          "inside the timed region; resident = uint8 dataset in HBM, staged = pinned uint8 batches over PCIe")
     ap.add_argument("--data-images", type=int, default=1024, help="images in the synthetic HDF5 file")
+    ap.add_argument("--attn-depth", type=int, default=1, help="0: shallower load batches in attn_context/dalpha (A/B)")
     ap.add_argument("--gemm-opts", default="", help="diagnostics: target,kmin,kmin_small of the split-K policy")
     ap.add_argument("--graph", action="store_true", help="replay the encoder as HIP graphs (measured slower)")
     args = ap.parse_args()
@@ -196,6 +197,7 @@ def main():
     if args.ksplit:
         SF.set_option("ksplit", args.ksplit)
     SF.set_option("chains", args.chains)
+    SF.set_option("attn_depth", args.attn_depth)
     if args.gemm_opts:
         for name, v in zip(("gemm_target", "gemm_kmin", "gemm_kmin_small", "gemm_gate"), args.gemm_opts.split(",")):
             SF.set_option(name, int(v))

@@ -16,6 +16,8 @@
 
 namespace scn {
 
+int g_attn_depth = 1;   // 1: deeper load batches in attn_context / attn_dalpha (option "attn_depth", A/B)
+
 namespace {
 
 constexpr int PC = 16;  // pixel rows per workgroup in the row-dot kernels (4 waves x 4 rows)
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(int rows, int P, int A
 
 // ------------------------------------------------------------------------------------------------
 // MODE 0: softmax-weighted sum (+ optional sigmoid gate).  MODE 1: plain mean over pixels.
-template <bool VEC, int MODE>
+template <bool VEC, int MODE, int CU>
 __global__ __launch_bounds__(512) void attn_context_kernel(int rows, int P, int E, const float* __restrict__ enc,
                                                            const float* __restrict__ e, Slabs gpre,
                                                            const float* __restrict__ bbeta,
@@ -109,8 +111,9 @@ __global__ __launch_bounds__(512) void attn_context_kernel(int rows, int P, int 
     const int b = blockIdx.y, e0 = blockIdx.x * 256;
 
     // The first batch of encoder rows does not depend on the softmax: put it in flight before the
-    // (barrier-heavy) softmax prologue.  CU = 8 rows per wave per batch -> 8 x 16 B loads in flight per lane.
-    constexpr int CU = 8;
+    // (barrier-heavy) softmax prologue.  CU rows per wave per batch -> CU x 16 B loads in flight per lane;
+    // a wave owns ceil(P/8) rows, and every extra batch is one more exposed memory latency, so the launcher
+    // picks CU = 13 for P = 196 (25 rows per wave -> 2 batches instead of 4 with CU = 8).
     const int col = e0 + lane * 4;
     const float* base = enc + (long)b * P * E;
     const int cc = min(col, max(E - 4, 0));
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(int rows, int P, int E,
 }
 
 // ------------------------------------------------------------------------------------------------
-template <bool VEC>
+template <bool VEC, int U>
 __global__ __launch_bounds__(256) void attn_dalpha_kernel(int rows, int P, int E, const float* __restrict__ enc,
                                                           const float* __restrict__ dawe,
                                                           const float* __restrict__ dalpha_in, long din_ld,
@@ -340,19 +343,20 @@ __global__ __launch_bounds__(256) void attn_dalpha_kernel(int rows, int P, int E
         rowp[j] = enc + ((long)b * P + (ok[j] ? p : P - 1)) * E;
     }
     if (VEC) {
-        // 2 column chunks x 4 rows = 8 x 16 B loads in flight per lane; the first batch is issued before
-        // the LDS staging of dawe (it does not depend on it)
-        f32x4 v[2][4];
+        // U column chunks x 4 rows = 4U x 16 B loads in flight per lane (U = 4 for E >= 1024: two batches
+        // cover a 2048-wide row instead of four); the first batch is issued before the LDS staging of dawe
+        // (it does not depend on it)
+        f32x4 v[U][4];
         const int cmax = E - 4;
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[u][j] = *reinterpret_cast<const f32x4*>(rowp[j] + min(lane * 4 + 256 * u, cmax));
         for (int c = tid; c < E4; c += 256) sm[c] = c < E ? dawe[(long)b * E + c] : 0.f;
         __syncthreads();
         for (int c0 = lane * 4;;) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const int c = c0 + 256 * u;
                 if (c < E) {
                     const f32x4 d = *reinterpret_cast<const f32x4*>(sm + c);
@@ -362,10 +366,10 @@ __global__ __launch_bounds__(256) void attn_dalpha_kernel(int rows, int P, int E
                         for (int k = 0; k < 4; ++k) acc[j] = fmaf(v[u][j][k], d[k], acc[j]);
                 }
             }
-            c0 += 512;
+            c0 += 256 * U;
             if (c0 >= E) break;
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[u][j] = *reinterpret_cast<const f32x4*>(rowp[j] + min(c0 + 256 * u, cmax));
         }
@@ -532,12 +536,19 @@ int attn_context(hipStream_t st, int rows, int P, int E, const float* enc, const
     dim3 grid(cdiv(E, 256), rows), block(512);
     const size_t lds = (8 * 256 + 16 + P) * sizeof(float);
     SCN_ARG(lds <= 64 * 1024, "attn_context: num_pixels too large for the LDS staging");
-    if (E % 4 == 0 && aligned16(enc))
-        hipLaunchKernelGGL((attn_context_kernel<true, 0>), grid, block, lds, st, rows, P, E, enc, e, gpre, bbeta,
+    const int rpw = cdiv(P, 8);          // encoder rows per wave
+    const bool deep = g_attn_depth && (rpw > 16 || (rpw > 8 && rpw <= 13));
+    if (E % 4 == 0 && aligned16(enc)) {
+        if (deep)
+            hipLaunchKernelGGL((attn_context_kernel<true, 0, 13>), grid, block, lds, st, rows, P, E, enc, e, gpre, bbeta,
+                               alpha_out, alpha_ld, alpha_save, awe, gate, z);
+        else
+            hipLaunchKernelGGL((attn_context_kernel<true, 0, 8>), grid, block, lds, st, rows, P, E, enc, e, gpre, bbeta,
+                               alpha_out, alpha_ld, alpha_save, awe, gate, z);
+    } else {
+        hipLaunchKernelGGL((attn_context_kernel<false, 0, 8>), grid, block, lds, st, rows, P, E, enc, e, gpre, bbeta,
                            alpha_out, alpha_ld, alpha_save, awe, gate, z);
-    else
-        hipLaunchKernelGGL((attn_context_kernel<false, 0>), grid, block, lds, st, rows, P, E, enc, e, gpre, bbeta,
-                           alpha_out, alpha_ld, alpha_save, awe, gate, z);
+    }
     SCN_LAUNCH_CHECK();
     return 0;
 }
@@ -549,11 +560,11 @@ int mean_pixels(hipStream_t st, int rows, int P, int E, const float* enc, float*
     const size_t lds = (8 * 256 + 16 + P) * sizeof(float);
     Slabs none{nullptr, 0, 0, 0};
     if (E % 4 == 0 && aligned16(enc))
-        hipLaunchKernelGGL((attn_context_kernel<true, 1>), grid, block, lds, st, rows, P, E, enc, (const float*)nullptr,
+        hipLaunchKernelGGL((attn_context_kernel<true, 1, 8>), grid, block, lds, st, rows, P, E, enc, (const float*)nullptr,
                            none, (const float*)nullptr, (float*)nullptr, 0L, (float*)nullptr, out, (float*)nullptr,
                            (float*)nullptr);
     else
-        hipLaunchKernelGGL((attn_context_kernel<false, 1>), grid, block, lds, st, rows, P, E, enc, (const float*)nullptr,
+        hipLaunchKernelGGL((attn_context_kernel<false, 1, 8>), grid, block, lds, st, rows, P, E, enc, (const float*)nullptr,
                            none, (const float*)nullptr, (float*)nullptr, 0L, (float*)nullptr, out, (float*)nullptr,
                            (float*)nullptr);
     SCN_LAUNCH_CHECK();
@@ -567,10 +578,14 @@ int attn_dalpha(hipStream_t st, int rows, int P, int E, const float* enc, const 
     dim3 grid(cdiv(P, PC), rows), block(256);
     const size_t lds = ((E + 3) & ~3) * sizeof(float);
     SCN_ARG(lds <= 64 * 1024, "attn_dalpha: encoder_dim too large for the LDS staging");
-    if (E % 4 == 0 && aligned16(enc))
-        hipLaunchKernelGGL(attn_dalpha_kernel<true>, grid, block, lds, st, rows, P, E, enc, dawe, dalpha_in, dalpha_in_ld, dalpha);
-    else
-        hipLaunchKernelGGL(attn_dalpha_kernel<false>, grid, block, lds, st, rows, P, E, enc, dawe, dalpha_in, dalpha_in_ld, dalpha);
+    if (E % 4 == 0 && aligned16(enc)) {
+        if (g_attn_depth && E >= 1024)
+            hipLaunchKernelGGL((attn_dalpha_kernel<true, 4>), grid, block, lds, st, rows, P, E, enc, dawe, dalpha_in, dalpha_in_ld, dalpha);
+        else
+            hipLaunchKernelGGL((attn_dalpha_kernel<true, 2>), grid, block, lds, st, rows, P, E, enc, dawe, dalpha_in, dalpha_in_ld, dalpha);
+    } else {
+        hipLaunchKernelGGL((attn_dalpha_kernel<false, 2>), grid, block, lds, st, rows, P, E, enc, dawe, dalpha_in, dalpha_in_ld, dalpha);
+    }
     SCN_LAUNCH_CHECK();
     return 0;
 }

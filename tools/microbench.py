@@ -12,6 +12,8 @@ from scnattn._lib import call, ptr, stream_of  # noqa: E402
 from scnattn import functional as SF  # noqa: E402
 
 dev = torch.device("cuda:0")
+if os.environ.get("ATTN_DEPTH"):
+    SF.set_option("attn_depth", int(os.environ["ATTN_DEPTH"]))
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
 B, P, E, A, D, F = 32, 196, 2048, 512, 512, 512
 F4 = 4 * F
