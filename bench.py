@@ -170,6 +170,9 @@ def main():
                          "*_IMAGES_*.hdf5 + JSON captions written to a temp dir) through scnattn.data.DeviceBatchLoader "
                          "inside the timed region; resident = uint8 dataset in HBM, staged = pinned uint8 batches over PCIe")
     ap.add_argument("--data-images", type=int, default=1024, help="images in the synthetic HDF5 file")
+    ap.add_argument("--dense-attention", action="store_true",
+                    help="A/B: attention over the materialised 14x14 pooled map (the reference's data flow) instead "
+                         "of the trunk's 8x8 source map (scnattn_pool)")
     ap.add_argument("--attn-depth", type=int, default=1, help="0: shallower load batches in attn_context/dalpha (A/B)")
     ap.add_argument("--gemm-opts", default="", help="diagnostics: target,kmin,kmin_small of the split-K policy")
     ap.add_argument("--graph", action="store_true", help="replay the encoder as HIP graphs (measured slower)")
@@ -197,6 +200,9 @@ def main():
     if args.ksplit:
         SF.set_option("ksplit", args.ksplit)
     SF.set_option("chains", args.chains)
+    if args.dense_attention:
+        from models.decoders import _common as _dec_common
+        _dec_common.USE_PREPOOL = False          # also ignore the map EncoderCaption attaches to its output
     SF.set_option("attn_depth", args.attn_depth)
     if args.gemm_opts:
         for name, v in zip(("gemm_target", "gemm_kmin", "gemm_kmin_small", "gemm_gate"), args.gemm_opts.split(",")):
@@ -211,13 +217,16 @@ def main():
         dist.barrier()                                    # first collective on every rank
     ts = TrainStep(kind=args.workload, fine_tune_encoder=fine_tune, device=dev, encoder=not args.decoder_only,
                    batch_size=args.batch, max_len=args.max_len, graph_encoder=args.graph, tagger=args.with_tagger, force_reduce=args.force_dist,
-                   encoder_dtype=args.encoder_dtype)
+                   encoder_dtype=args.encoder_dtype, pooled_attention=not args.dense_attention)
     cfg = ts.cfg
     imgs, tags, caps, caplens = synthetic_batch(args.batch, cfg["vocab_size"], cfg["max_len"], cfg["image_size"],
                                                 cfg["semantic_dim"], dev, 1234 + rank)
-    enc_in = None
+    enc_in = pre_in = None
     if args.decoder_only:
-        enc_in = torch.rand(args.batch, 14, 14, 2048, device=dev)
+        if args.workload == "attention_scn" and not args.dense_attention:
+            pre_in = torch.rand(args.batch, 8, 8, 2048, device=dev)     # the trunk's map at 256x256 input
+        else:
+            enc_in = torch.rand(args.batch, 14, 14, 2048, device=dev)
 
     batches = None
     if args.data != "synthetic":
@@ -230,9 +239,10 @@ def main():
                 imgs, caps, caplens = next(batches)
             if args.forward_only:
                 with torch.no_grad():
-                    ts.decoder(enc_in, tags, caps, caplens)
+                    ts.decoder(enc_in, tags, caps, caplens, prepool=pre_in) if pre_in is not None else \
+                        ts.decoder(enc_in, tags, caps, caplens)
             else:
-                ts.step(imgs, tags, caps, caplens, enc_in)
+                ts.step(imgs, tags, caps, caplens, enc_in, pre_in)
 
     run(args.warmup)
     SF.set_option("profile", 1)
@@ -295,23 +305,35 @@ def main():
             ab = step_bytes(cfg, args.batch)
             ach = ab / (step_us * 1e-6) / 1e9
             traffic, tsrc = None, None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_decode_step_fwd.json")
+            pooled = not args.dense_attention
+            pmc_name = "r01_pmc_decode_step_fwd_%s.json" % ("pooled" if pooled else "dense")
+            pmc = os.path.join(ROOT, "profiles", pmc_name)
             if args.batch == 32 and os.path.exists(pmc):   # PMC passes cannot run inside this process;
                 with open(pmc) as fh:                        # the committed rocprofv3 result is quoted
                     traffic = json.load(fh).get("hbm_bytes_per_step")
-                tsrc = "profiles/r01_pmc_decode_step_fwd.json (separate rocprofv3 --pmc passes)"
+                tsrc = "profiles/%s (separate rocprofv3 --pmc passes)" % pmc_name
+            # `achieved` prices the step at SURVEY 8d's algorithmic bytes (the reference's formulation: the pooled
+            # 14x14 map is read every step).  The pooled path moves fewer: the context reads the 8x8 source map.
+            eb = step_bytes(cfg, args.batch, P=64) + 4 * args.batch * (196 - 64) * cfg["attention_dim"] if pooled else ab
+            ach_e = eb / (step_us * 1e-6) / 1e9
+            ctx_bytes = 4 * args.batch * (64 if pooled else 196) * 2048
             out["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
                                "kernel": "decode step fwd = skinny_kernel x3 + attn_scores + attn_context + "
                                          "scn_mix_fwd + lstm_fwd (the fused SCN-cell+attention step)",
                                "algorithmic_bytes_per_step": ab, "avg_step_us": round(step_us, 2),
+                               "executed_bytes_per_step": eb, "achieved_on_executed_bytes": round(ach_e, 1),
+                               "frac_on_executed_bytes": round(ach_e / HBM_PEAK_GBS, 4),
+                               "attention_path": "pooled: context / d alpha over the trunk's 8x8 map (scnattn_pool), "
+                                                 "same numbers by linearity of the average pool" if pooled else
+                                                 "dense: over the materialised 14x14 pooled map, as the reference",
                                "dominant_single_kernel": None if ctx_us is None else {
                                    "name": "attn_context_kernel (softmax + sum_p alpha*enc + gate)",
                                    "launches_per_step": round(ctx_per_step, 2),
-                                   "algorithmic_bytes": int(4 * args.batch * 196 * 2048 / ctx_per_step),
+                                   "algorithmic_bytes": int(ctx_bytes / ctx_per_step),
                                    "avg_us": round(ctx_us, 2),
-                                   "achieved_GBs": round(4 * args.batch * 196 * 2048 / ctx_per_step / (ctx_us * 1e-6) / 1e9, 1),
-                                   "frac": round(4 * args.batch * 196 * 2048 / ctx_per_step / (ctx_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                   "achieved_GBs": round(ctx_bytes / ctx_per_step / (ctx_us * 1e-6) / 1e9, 1),
+                                   "frac": round(ctx_bytes / ctx_per_step / (ctx_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                    "note": None if ctx_per_step < 1.5 else
                                    "with 2 chains the two half-batch launches overlap other kernels of the "
                                    "sibling chain, so the per-launch time is not a standalone figure"},

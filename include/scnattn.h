@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SCNATTN_VERSION 100 /* 0.1.0 */
+#define SCNATTN_VERSION 101 /* 0.1.1: scnattn_pool argument of the sequence drivers */
 
 int scnattn_version(void);
 const char* scnattn_last_error(void);
@@ -83,16 +83,37 @@ typedef struct {
     float* fc_bias;                      /* [V]                            */
 } scnattn_params;
 
-/* Bytes of the two workspaces of the sequence drivers.  `saved` carries forward state to the
- * backward pass; `scratch` is free after each call.  Both must be zero-filled by the caller before
- * scnattn_seq_fwd (saved) / each call (scratch). */
-int scnattn_seq_workspace(const scnattn_dims* d, size_t* saved_bytes, size_t* scratch_bytes);
+/* Optional: encoder_out described as a FIXED LINEAR POOLING of a smaller feature map x [B,Q,E] -- what
+ * models/encoders/caption.py:41-43 produces (AdaptiveAvgPool2d(14) of the trunk's 8x8 map at 256x256 input,
+ * an up-sampling 1-or-2-tap average, then permute):
+ *     enc[b][p][:] = sum_{k<4} tap_w[p][k] * x[b][tap_idx[p][k]][:]        (unused taps: weight 0, index 0)
+ * With it the sequence drivers take x in place of enc and never materialise the pooled map: by linearity
+ * encoder_att runs on Q rows (att1 = pool(x.We^T) + be), the attention context and its gradient read Q rows
+ * per image instead of P (sum_p alpha_p enc_p = sum_q alphaq_q x_q, alphaq = pool^T alpha), and d x comes out
+ * directly.  SURVEY.md 8d names this shortcut.  All tables live in device memory.
+ *   qtap_*: the transpose -- for source pixel q the (p, weight) pairs that read it, padded with index -1;
+ *   col_w[q] = (sum_p weight(p,q)) / P, so that mean_p enc[b][p] = sum_q col_w[q] x[b][q]. */
+typedef struct scnattn_pool {
+    int Q;                   /* source pixels per image (Q <= P) */
+    int qtap_max;            /* row length of qtap_idx / qtap_w (<= 64) */
+    const int32_t* tap_idx;  /* [P][4] */
+    const float* tap_w;      /* [P][4] */
+    const int32_t* qtap_idx; /* [Q][qtap_max] */
+    const float* qtap_w;     /* [Q][qtap_max] */
+    const float* col_w;      /* [Q] */
+} scnattn_pool;
+
+/* Bytes of the two workspaces of the sequence drivers (pool may be NULL).  `saved` carries forward state to
+ * the backward pass; `scratch` is free after each call.  Both must be zero-filled by the caller before
+ * scnattn_seq_fwd (saved) / each call (scratch) unless every caption decodes at every step (bt_host[T-1] == B),
+ * in which case every element is written before it is read. */
+int scnattn_seq_workspace(const scnattn_dims* d, const scnattn_pool* pool, size_t* saved_bytes, size_t* scratch_bytes);
 
 /* Teacher-forced decoder forward over all T steps: replaces the loop of
  * models/decoders/attention_scn.py:124-156 (pure_scn.py:114-138 when has_att == 0), i.e. per step
  * Attention.forward (models/attention.py:35-44), the f_beta gate, SCNCell.forward/recurrent_step
  * (models/scn_cell.py:62-154), dropout and fc.
- *   enc     [B,P,E]  encoder output, rows already permuted by sort_ind
+ *   enc     [B,P,E]  encoder output, rows already permuted by sort_ind ([B,Q,E] = x when pool != NULL)
  *   tags    [B,S]    semantic input, NOT permuted (reference quirk, attention_scn.py:152)
  *   caps    [B,L]    int64 sorted captions;  dl_dev [B] int32 decode lengths (device)
  *   bt_host [T]      host array: active rows at step t (non-increasing)
@@ -101,15 +122,17 @@ int scnattn_seq_workspace(const scnattn_dims* d, size_t* saved_bytes, size_t* sc
  *   alphas  [B,T,P]  out, must be zero-filled by the caller (NULL when has_att == 0) */
 int scnattn_seq_fwd(void* stream, const scnattn_dims* d, const scnattn_params* w, const float* enc,
                     const float* tags, const int64_t* caps, const int32_t* dl_dev, const int32_t* bt_host,
-                    const float* drop_mask, float* saved, float* scratch, float* preds, float* alphas);
+                    const float* drop_mask, float* saved, float* scratch, float* preds, float* alphas,
+                    const scnattn_pool* pool);
 
 /* Gradient of scnattn_seq_fwd (what autograd derives for the reference's loop).  `g` receives
  * d loss / d parameter (fields may be NULL to skip; embedding_weight must be zero-filled: rows
- * are accumulated).  denc [B,P,E] and dtags [B,S] may be NULL. */
+ * are accumulated).  denc [B,P,E] ([B,Q,E] = d x when pool != NULL) and dtags [B,S] may be NULL. */
 int scnattn_seq_bwd(void* stream, const scnattn_dims* d, const scnattn_params* w, const float* enc,
                     const float* tags, const int64_t* caps, const int32_t* dl_dev, const int32_t* bt_host,
                     const float* drop_mask, const float* saved, float* scratch, const float* dpreds,
-                    const float* dalphas, const scnattn_params* g, float* denc, float* dtags);
+                    const float* dalphas, const scnattn_params* g, float* denc, float* dtags,
+                    const scnattn_pool* pool);
 
 /* ---- primitives (each = one kernel launch); used by the stand-alone modules and the tests ------- */
 /* C = alpha*op(A).op(B) + beta*C + bias[n]; rows with rowmask[m]==0 written as 0.  Replaces the

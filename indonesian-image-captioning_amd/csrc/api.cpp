@@ -26,14 +26,14 @@ extern int g_chains;
 extern int g_attn_depth;
 extern int g_gemm_target, g_gemm_kmin, g_gemm_kmin_small, g_gemm_gate;
 int profile_collect(double* out);
-int seq_workspace(const scnattn_dims* d, size_t* saved_bytes, size_t* scratch_bytes);
+int seq_workspace(const scnattn_dims* d, const scnattn_pool* pool, size_t* saved_bytes, size_t* scratch_bytes);
 int seq_fwd(hipStream_t st, const scnattn_dims* d, const scnattn_params* w, const float* enc, const float* tags,
             const int64_t* caps, const int32_t* dl_dev, const int32_t* bt, const float* drop_mask, float* saved,
-            float* scratch, float* preds, float* alphas);
+            float* scratch, float* preds, float* alphas, const scnattn_pool* pool);
 int seq_bwd(hipStream_t st, const scnattn_dims* d, const scnattn_params* w, const float* enc, const float* tags,
             const int64_t* caps, const int32_t* dl_dev, const int32_t* bt, const float* drop_mask, const float* saved,
             float* scratch, const float* dpreds, const float* dalphas, const scnattn_params* g, float* denc,
-            float* dtags);
+            float* dtags, const scnattn_pool* pool);
 
 }  // namespace scn
 
@@ -77,22 +77,24 @@ int scnattn_profile_collect(double* out6) {
     return profile_collect(out6);
 }
 
-int scnattn_seq_workspace(const scnattn_dims* d, size_t* saved_bytes, size_t* scratch_bytes) {
-    return seq_workspace(d, saved_bytes, scratch_bytes);
+int scnattn_seq_workspace(const scnattn_dims* d, const scnattn_pool* pool, size_t* saved_bytes, size_t* scratch_bytes) {
+    return seq_workspace(d, pool, saved_bytes, scratch_bytes);
 }
 
 int scnattn_seq_fwd(void* stream, const scnattn_dims* d, const scnattn_params* w, const float* enc,
                     const float* tags, const int64_t* caps, const int32_t* dl_dev, const int32_t* bt_host,
-                    const float* drop_mask, float* saved, float* scratch, float* preds, float* alphas) {
-    return seq_fwd(ST(stream), d, w, enc, tags, caps, dl_dev, bt_host, drop_mask, saved, scratch, preds, alphas);
+                    const float* drop_mask, float* saved, float* scratch, float* preds, float* alphas,
+                    const scnattn_pool* pool) {
+    return seq_fwd(ST(stream), d, w, enc, tags, caps, dl_dev, bt_host, drop_mask, saved, scratch, preds, alphas, pool);
 }
 
 int scnattn_seq_bwd(void* stream, const scnattn_dims* d, const scnattn_params* w, const float* enc,
                     const float* tags, const int64_t* caps, const int32_t* dl_dev, const int32_t* bt_host,
                     const float* drop_mask, const float* saved, float* scratch, const float* dpreds,
-                    const float* dalphas, const scnattn_params* g, float* denc, float* dtags) {
+                    const float* dalphas, const scnattn_params* g, float* denc, float* dtags,
+                    const scnattn_pool* pool) {
     return seq_bwd(ST(stream), d, w, enc, tags, caps, dl_dev, bt_host, drop_mask, saved, scratch, dpreds, dalphas, g,
-                   denc, dtags);
+                   denc, dtags, pool);
 }
 
 int scnattn_sgemm(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A,

@@ -95,33 +95,46 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(int rows, int P, int A
 }
 
 // ------------------------------------------------------------------------------------------------
-// MODE 0: softmax-weighted sum (+ optional sigmoid gate).  MODE 1: plain mean over pixels.
-template <bool VEC, int MODE, int CU>
+// MODE 0: softmax-weighted sum (+ optional sigmoid gate).  MODE 1: plain mean over pixels.  MODE 2: sum with
+// the given per-row weights `e` (not per batch row).
+// POOLED (MODE 0): encoder_out is a fixed linear pooling of a smaller map x [B][Q][E] (scnattn_pool): the
+// softmax still runs over the P pooled pixels, then alpha is folded back onto the Q source pixels,
+// alphaq[q] = sum_k qtap_w[q][k] * alpha[qtap_idx[q][k]]  (deterministic gather), and the context is
+// sum_q alphaq[q] * x[q] -- the same number by linearity, read from Q rows instead of P.
+struct PoolQ {
+    int Q, qtap_max;
+    const int* qtap_idx;
+    const float* qtap_w;
+    float* alphaq_save;     // [rows][Q]
+};
+
+template <bool VEC, int MODE, int CU, bool POOLED>
 __global__ __launch_bounds__(512) void attn_context_kernel(int rows, int P, int E, const float* __restrict__ enc,
                                                            const float* __restrict__ e, Slabs gpre,
                                                            const float* __restrict__ bbeta,
                                                            float* __restrict__ alpha_out, long alpha_ld,
                                                            float* __restrict__ alpha_save, float* __restrict__ awe,
-                                                           float* __restrict__ gate, float* __restrict__ z) {
+                                                           float* __restrict__ gate, float* __restrict__ z, PoolQ pq) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* part = sm;              // [8][256]
     float* red = sm + 8 * 256;     // [16]
-    float* alph = red + 16;        // [P]
+    float* alph = red + 16;        // [P]   (then [Q] more when POOLED)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, e0 = blockIdx.x * 256;
+    const int NR = POOLED ? pq.Q : P;          // rows of the map that is actually summed
 
     // The first batch of encoder rows does not depend on the softmax: put it in flight before the
     // (barrier-heavy) softmax prologue.  CU rows per wave per batch -> CU x 16 B loads in flight per lane;
     // a wave owns ceil(P/8) rows, and every extra batch is one more exposed memory latency, so the launcher
     // picks CU = 13 for P = 196 (25 rows per wave -> 2 batches instead of 4 with CU = 8).
     const int col = e0 + lane * 4;
-    const float* base = enc + (long)b * P * E;
+    const float* base = enc + (long)b * NR * E;
     const int cc = min(col, max(E - 4, 0));
     const bool cok = col < E;
     f32x4 v[CU];
     if (VEC) {
 #pragma unroll
-        for (int j = 0; j < CU; ++j) v[j] = *reinterpret_cast<const f32x4*>(base + (long)min(wave + 8 * j, P - 1) * E + cc);
+        for (int j = 0; j < CU; ++j) v[j] = *reinterpret_cast<const f32x4*>(base + (long)min(wave + 8 * j, NR - 1) * E + cc);
     }
 
     if (MODE == 0) {
@@ -145,6 +158,25 @@ __global__ __launch_bounds__(512) void attn_context_kernel(int rows, int P, int 
         }
         __syncthreads();
     }
+    if (MODE == 2) {
+        for (int p = tid; p < NR; p += 512) alph[p] = e[p];
+        __syncthreads();
+    }
+    const float* wts = alph;
+    if (POOLED) {
+        float* aq = alph + P;
+        for (int q = tid; q < pq.Q; q += 512) {
+            float a = 0.f;
+            for (int k = 0; k < pq.qtap_max; ++k) {
+                const int pi = pq.qtap_idx[q * pq.qtap_max + k];
+                if (pi >= 0) a = fmaf(pq.qtap_w[q * pq.qtap_max + k], alph[pi], a);
+            }
+            aq[q] = a;
+            if (blockIdx.x == 0 && pq.alphaq_save) pq.alphaq_save[(long)b * pq.Q + q] = a;
+        }
+        __syncthreads();
+        wts = aq;
+    }
 
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     if (VEC) {
@@ -153,21 +185,21 @@ __global__ __launch_bounds__(512) void attn_context_kernel(int rows, int P, int 
 #pragma unroll
             for (int j = 0; j < CU; ++j) {
                 const int pp = p + 8 * j;
-                al[j] = (pp < P && cok) ? (MODE == 0 ? alph[min(pp, P - 1)] : 1.f) : 0.f;
+                al[j] = (pp < NR && cok) ? (MODE != 1 ? wts[min(pp, NR - 1)] : 1.f) : 0.f;
             }
 #pragma unroll
             for (int j = 0; j < CU; ++j)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[c] = fmaf(al[j], v[j][c], acc[c]);
             p += 8 * CU;
-            if (p >= P) break;
+            if (p >= NR) break;
 #pragma unroll
             for (int j = 0; j < CU; ++j)
-                v[j] = *reinterpret_cast<const f32x4*>(base + (long)min(p + 8 * j, P - 1) * E + cc);
+                v[j] = *reinterpret_cast<const f32x4*>(base + (long)min(p + 8 * j, NR - 1) * E + cc);
         }
     } else {
-        for (int p = wave; p < P; p += 8) {
-            const float al = MODE == 0 ? alph[p] : 1.f;
+        for (int p = wave; p < NR; p += 8) {
+            const float al = MODE != 1 ? wts[p] : 1.f;
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 if (col + c < E) acc[c] = fmaf(al, base[(long)p * E + col + c], acc[c]);
@@ -184,6 +216,8 @@ __global__ __launch_bounds__(512) void attn_context_kernel(int rows, int P, int 
             for (int w8 = 1; w8 < 8; ++w8) a += part[w8 * 256 + tid];
             if (MODE == 1) {
                 awe[(long)b * E + c] = a / (float)P;
+            } else if (MODE == 2) {
+                awe[(long)b * E + c] = a;
             } else {
                 awe[(long)b * E + c] = a;
                 if (gpre.p) {
@@ -391,6 +425,15 @@ __global__ __launch_bounds__(256) void attn_dalpha_kernel(int rows, int P, int E
 }
 
 // ------------------------------------------------------------------------------------------------
+struct DalphaTaps {      // pooled path: d alpha is gathered from the Q source-pixel dot products
+    const int* tap_idx;  // [P][4] or NULL (dense dalpha)
+    const float* tap_w;  // [P][4]
+    const float* dalphaq;  // [rows][Q]
+    int Q;
+    const float* din;    // upstream d alphas [rows][din_ld] or NULL
+    long din_ld;
+};
+
 template <bool VEC>
 __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(int rows, int P, int A, const float* __restrict__ att1,
                                                                const float* __restrict__ att2,
@@ -398,7 +441,7 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(int rows, int P, 
                                                                const float* __restrict__ alpha,
                                                                const float* __restrict__ dalpha,
                                                                float* __restrict__ de, float* __restrict__ datt2,
-                                                               long datt2_ld) {
+                                                               long datt2_ld, DalphaTaps dt) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* part = sm;              // [16][64]
     float* red = sm + 16 * 64;     // [16]
@@ -406,10 +449,22 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(int rows, int P, 
     const int tid = threadIdx.x;
     const int b = blockIdx.y, a0 = blockIdx.x * 64;
     float dot = 0.f;
-    for (int p = tid; p < P; p += 256) dot = fmaf(alpha[(long)b * P + p], dalpha[(long)b * P + p], dot);
+    for (int p = tid; p < P; p += 256) {
+        float da;
+        if (dt.tap_idx) {          // d alpha[p] = sum_k tap_w[p][k] * d alphaq[tap_idx[p][k]] (+ upstream d alphas)
+            da = dt.din ? dt.din[(long)b * dt.din_ld + p] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                da = fmaf(dt.tap_w[p * 4 + k], dt.dalphaq[(long)b * dt.Q + dt.tap_idx[p * 4 + k]], da);
+        } else {
+            da = dalpha[(long)b * P + p];
+        }
+        des[p] = da;
+        dot = fmaf(alpha[(long)b * P + p], da, dot);
+    }
     dot = block_reduce(dot, red, false);
     for (int p = tid; p < P; p += 256) {
-        const float d = alpha[(long)b * P + p] * (dalpha[(long)b * P + p] - dot);
+        const float d = alpha[(long)b * P + p] * (des[p] - dot);
         des[p] = d;
         if (blockIdx.x == 0 && de) de[(long)b * P + p] = d;
     }
@@ -538,17 +593,66 @@ int attn_context(hipStream_t st, int rows, int P, int E, const float* enc, const
     SCN_ARG(lds <= 64 * 1024, "attn_context: num_pixels too large for the LDS staging");
     const int rpw = cdiv(P, 8);          // encoder rows per wave
     const bool deep = g_attn_depth && (rpw > 16 || (rpw > 8 && rpw <= 13));
+    const PoolQ none{0, 0, nullptr, nullptr, nullptr};
     if (E % 4 == 0 && aligned16(enc)) {
         if (deep)
-            hipLaunchKernelGGL((attn_context_kernel<true, 0, 13>), grid, block, lds, st, rows, P, E, enc, e, gpre, bbeta,
-                               alpha_out, alpha_ld, alpha_save, awe, gate, z);
+            hipLaunchKernelGGL((attn_context_kernel<true, 0, 13, false>), grid, block, lds, st, rows, P, E, enc, e, gpre,
+                               bbeta, alpha_out, alpha_ld, alpha_save, awe, gate, z, none);
         else
-            hipLaunchKernelGGL((attn_context_kernel<true, 0, 8>), grid, block, lds, st, rows, P, E, enc, e, gpre, bbeta,
-                               alpha_out, alpha_ld, alpha_save, awe, gate, z);
+            hipLaunchKernelGGL((attn_context_kernel<true, 0, 8, false>), grid, block, lds, st, rows, P, E, enc, e, gpre,
+                               bbeta, alpha_out, alpha_ld, alpha_save, awe, gate, z, none);
     } else {
-        hipLaunchKernelGGL((attn_context_kernel<false, 0, 8>), grid, block, lds, st, rows, P, E, enc, e, gpre, bbeta,
-                           alpha_out, alpha_ld, alpha_save, awe, gate, z);
+        hipLaunchKernelGGL((attn_context_kernel<false, 0, 8, false>), grid, block, lds, st, rows, P, E, enc, e, gpre,
+                           bbeta, alpha_out, alpha_ld, alpha_save, awe, gate, z, none);
     }
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
+// attn_context over the un-pooled map x [rows][Q][E] (see PoolQ)
+int attn_context_pooled(hipStream_t st, int rows, int P, int E, const float* x, const PoolDesc& pool, const float* e,
+                        Slabs gpre, const float* bbeta, float* alpha_out, long alpha_ld, float* alpha_save,
+                        float* alphaq_save, float* awe, float* gate, float* z) {
+    if (rows <= 0) return 0;
+    SCN_ARG(x && e && awe && P > 0 && E > 0 && pool.Q > 0 && pool.qtap_idx && pool.qtap_w, "attn_context_pooled: bad argument");
+    dim3 grid(cdiv(E, 256), rows), block(512);
+    const size_t lds = (8 * 256 + 16 + P + pool.Q) * sizeof(float);
+    SCN_ARG(lds <= 64 * 1024, "attn_context: num_pixels too large for the LDS staging");
+    const PoolQ pq{pool.Q, pool.qtap_max, pool.qtap_idx, pool.qtap_w, alphaq_save};
+    const int rpw = cdiv(pool.Q, 8);
+    const bool deep = g_attn_depth && (rpw > 16 || (rpw > 8 && rpw <= 13));
+    if (E % 4 == 0 && aligned16(x)) {
+        if (deep)
+            hipLaunchKernelGGL((attn_context_kernel<true, 0, 13, true>), grid, block, lds, st, rows, P, E, x, e, gpre,
+                               bbeta, alpha_out, alpha_ld, alpha_save, awe, gate, z, pq);
+        else
+            hipLaunchKernelGGL((attn_context_kernel<true, 0, 8, true>), grid, block, lds, st, rows, P, E, x, e, gpre,
+                               bbeta, alpha_out, alpha_ld, alpha_save, awe, gate, z, pq);
+    } else {
+        hipLaunchKernelGGL((attn_context_kernel<false, 0, 8, true>), grid, block, lds, st, rows, P, E, x, e, gpre,
+                           bbeta, alpha_out, alpha_ld, alpha_save, awe, gate, z, pq);
+    }
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
+// out[b][:] = sum_q wts[q] * x[b][q][:]   (e.g. the pixel mean of the pooled map: wts = column sums of the pool / P)
+int weighted_rows(hipStream_t st, int rows, int Q, int E, const float* x, const float* wts, float* out) {
+    if (rows <= 0) return 0;
+    SCN_ARG(x && wts && out && Q > 0 && E > 0, "weighted_rows: bad argument");
+    dim3 grid(cdiv(E, 256), rows), block(512);
+    const size_t lds = (8 * 256 + 16 + Q) * sizeof(float);
+    SCN_ARG(lds <= 64 * 1024, "weighted_rows: too many rows for the LDS staging");
+    Slabs nos{nullptr, 0, 0, 0};
+    const PoolQ none{0, 0, nullptr, nullptr, nullptr};
+    if (E % 4 == 0 && aligned16(x))
+        hipLaunchKernelGGL((attn_context_kernel<true, 2, 8, false>), grid, block, lds, st, rows, Q, E, x, wts, nos,
+                           (const float*)nullptr, (float*)nullptr, 0L, (float*)nullptr, out, (float*)nullptr,
+                           (float*)nullptr, none);
+    else
+        hipLaunchKernelGGL((attn_context_kernel<false, 2, 8, false>), grid, block, lds, st, rows, Q, E, x, wts, nos,
+                           (const float*)nullptr, (float*)nullptr, 0L, (float*)nullptr, out, (float*)nullptr,
+                           (float*)nullptr, none);
     SCN_LAUNCH_CHECK();
     return 0;
 }
@@ -560,13 +664,13 @@ int mean_pixels(hipStream_t st, int rows, int P, int E, const float* enc, float*
     const size_t lds = (8 * 256 + 16 + P) * sizeof(float);
     Slabs none{nullptr, 0, 0, 0};
     if (E % 4 == 0 && aligned16(enc))
-        hipLaunchKernelGGL((attn_context_kernel<true, 1, 8>), grid, block, lds, st, rows, P, E, enc, (const float*)nullptr,
+        hipLaunchKernelGGL((attn_context_kernel<true, 1, 8, false>), grid, block, lds, st, rows, P, E, enc, (const float*)nullptr,
                            none, (const float*)nullptr, (float*)nullptr, 0L, (float*)nullptr, out, (float*)nullptr,
-                           (float*)nullptr);
+                           (float*)nullptr, PoolQ{0, 0, nullptr, nullptr, nullptr});
     else
-        hipLaunchKernelGGL((attn_context_kernel<false, 1, 8>), grid, block, lds, st, rows, P, E, enc, (const float*)nullptr,
+        hipLaunchKernelGGL((attn_context_kernel<false, 1, 8, false>), grid, block, lds, st, rows, P, E, enc, (const float*)nullptr,
                            none, (const float*)nullptr, (float*)nullptr, 0L, (float*)nullptr, out, (float*)nullptr,
-                           (float*)nullptr);
+                           (float*)nullptr, PoolQ{0, 0, nullptr, nullptr, nullptr});
     SCN_LAUNCH_CHECK();
     return 0;
 }
@@ -598,10 +702,125 @@ int attn_softmax_bwd(hipStream_t st, int rows, int P, int A, const float* att1, 
     dim3 grid(cdiv(A, 64), rows), block(256);
     const size_t lds = (16 * 64 + 16 + P) * sizeof(float);
     SCN_ARG(lds <= 64 * 1024, "attn_softmax_bwd: num_pixels too large for the LDS staging");
+    const DalphaTaps none{nullptr, nullptr, nullptr, 0, nullptr, 0};
     if (A % 4 == 0 && aligned16(att1))
-        hipLaunchKernelGGL(attn_softmax_bwd_kernel<true>, grid, block, lds, st, rows, P, A, att1, att2, w, alpha, dalpha, de, datt2, datt2_ld);
+        hipLaunchKernelGGL(attn_softmax_bwd_kernel<true>, grid, block, lds, st, rows, P, A, att1, att2, w, alpha, dalpha, de, datt2, datt2_ld, none);
     else
-        hipLaunchKernelGGL(attn_softmax_bwd_kernel<false>, grid, block, lds, st, rows, P, A, att1, att2, w, alpha, dalpha, de, datt2, datt2_ld);
+        hipLaunchKernelGGL(attn_softmax_bwd_kernel<false>, grid, block, lds, st, rows, P, A, att1, att2, w, alpha, dalpha, de, datt2, datt2_ld, none);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
+// softmax backward whose d alpha comes from the source-pixel dot products dalphaq [rows][Q] through the pool taps
+int attn_softmax_bwd_pooled(hipStream_t st, int rows, int P, int A, const float* att1, const float* att2, const float* w,
+                            const float* alpha, const PoolDesc& pool, const float* dalphaq, const float* dalpha_in,
+                            long dalpha_in_ld, float* de, float* datt2, long datt2_ld) {
+    if (rows <= 0) return 0;
+    SCN_ARG(att1 && att2 && w && alpha && dalphaq && datt2 && P > 0 && A > 0 && pool.tap_idx && pool.tap_w,
+            "attn_softmax_bwd_pooled: bad argument");
+    dim3 grid(cdiv(A, 64), rows), block(256);
+    const size_t lds = (16 * 64 + 16 + P) * sizeof(float);
+    SCN_ARG(lds <= 64 * 1024, "attn_softmax_bwd: num_pixels too large for the LDS staging");
+    const DalphaTaps dt{pool.tap_idx, pool.tap_w, dalphaq, pool.Q, dalpha_in, dalpha_in_ld};
+    if (A % 4 == 0 && aligned16(att1))
+        hipLaunchKernelGGL(attn_softmax_bwd_kernel<true>, grid, block, lds, st, rows, P, A, att1, att2, w, alpha, (const float*)nullptr, de, datt2, datt2_ld, dt);
+    else
+        hipLaunchKernelGGL(attn_softmax_bwd_kernel<false>, grid, block, lds, st, rows, P, A, att1, att2, w, alpha, (const float*)nullptr, de, datt2, datt2_ld, dt);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- small helpers of the pooled path ---------------------------------------------------------------
+namespace {
+
+// out[b][p][:] = sum_k tap_w[p][k] * y[b][tap_idx[p][k]][:] + bias      (att1 from y = x . We^T)
+__global__ __launch_bounds__(256) void pool_expand_kernel(long n4, int P, int Q, int A4, const int* __restrict__ tap_idx,
+                                                          const float* __restrict__ tap_w, const float* __restrict__ y,
+                                                          const float* __restrict__ bias, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int a4 = (int)(i % A4);
+    const long bp = i / A4;
+    const int p = (int)(bp % P);
+    const long b = bp / P;
+    f32x4 acc = bias ? *reinterpret_cast<const f32x4*>(bias + a4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float wk = tap_w[p * 4 + k];
+        const f32x4 v = *reinterpret_cast<const f32x4*>(y + ((b * Q + tap_idx[p * 4 + k]) * A4 + a4) * 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = fmaf(wk, v[c], acc[c]);
+    }
+    *reinterpret_cast<f32x4*>(out + i * 4) = acc;
+}
+
+// out[b][q][:] = sum_k qtap_w[q][k] * in[b][qtap_idx[q][k]][:]           (transpose of the pooling, e.g. d y from d att1)
+__global__ __launch_bounds__(256) void pool_transpose_kernel(long n4, int P, int Q, int A4, int qmax,
+                                                             const int* __restrict__ qtap_idx,
+                                                             const float* __restrict__ qtap_w, const float* __restrict__ in,
+                                                             float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int a4 = (int)(i % A4);
+    const long bq = i / A4;
+    const int q = (int)(bq % Q);
+    const long b = bq / Q;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < qmax; ++k) {
+        const int pi = qtap_idx[q * qmax + k];
+        if (pi < 0) continue;
+        const float wk = qtap_w[q * qmax + k];
+        const f32x4 v = *reinterpret_cast<const f32x4*>(in + ((b * P + pi) * A4 + a4) * 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = fmaf(wk, v[c], acc[c]);
+    }
+    *reinterpret_cast<f32x4*>(out + i * 4) = acc;
+}
+
+// out[b][q][:] += wts[q] * v[b][:]
+__global__ __launch_bounds__(256) void add_bcast_rows_w_kernel(long n4, int Q, int E4, const float* __restrict__ wts,
+                                                               const float* __restrict__ v, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int e4 = (int)(i % E4);
+    const long bq = i / E4;
+    const int q = (int)(bq % Q);
+    const long b = bq / Q;
+    const float wq = wts[q];
+    const f32x4 x = *reinterpret_cast<const f32x4*>(v + (b * E4 + e4) * 4);
+    f32x4 o = *reinterpret_cast<f32x4*>(out + i * 4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = fmaf(wq, x[c], o[c]);
+    *reinterpret_cast<f32x4*>(out + i * 4) = o;
+}
+
+}  // namespace
+
+int pool_expand(hipStream_t st, int B, int P, int A, const PoolDesc& pool, const float* y, const float* bias, float* out) {
+    SCN_ARG(B > 0 && P > 0 && A > 0 && A % 4 == 0 && y && out && pool.tap_idx && pool.tap_w && aligned16(y) && aligned16(out),
+            "pool_expand: bad argument (A must be a multiple of 4)");
+    const long n4 = (long)B * P * (A / 4);
+    hipLaunchKernelGGL(pool_expand_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, n4, P, pool.Q, A / 4, pool.tap_idx,
+                       pool.tap_w, y, bias, out);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
+int pool_transpose(hipStream_t st, int B, int P, int A, const PoolDesc& pool, const float* in, float* out) {
+    SCN_ARG(B > 0 && P > 0 && A > 0 && A % 4 == 0 && in && out && pool.qtap_idx && pool.qtap_w && aligned16(in) &&
+                aligned16(out), "pool_transpose: bad argument (A must be a multiple of 4)");
+    const long n4 = (long)B * pool.Q * (A / 4);
+    hipLaunchKernelGGL(pool_transpose_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, n4, P, pool.Q, A / 4, pool.qtap_max,
+                       pool.qtap_idx, pool.qtap_w, in, out);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
+int add_bcast_rows_w(hipStream_t st, int B, int Q, int E, const float* wts, const float* v, float* out) {
+    SCN_ARG(B > 0 && Q > 0 && E > 0 && E % 4 == 0 && wts && v && out && aligned16(v) && aligned16(out),
+            "add_bcast_rows_w: bad argument (E must be a multiple of 4)");
+    const long n4 = (long)B * Q * (E / 4);
+    hipLaunchKernelGGL(add_bcast_rows_w_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, n4, Q, E / 4, wts, v, out);
     SCN_LAUNCH_CHECK();
     return 0;
 }

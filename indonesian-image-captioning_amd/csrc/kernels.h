@@ -46,6 +46,25 @@ int attn_fused(hipStream_t st, int rows, int P, int E, int A, const float* enc, 
                long alpha_ld, float* alpha_save, float* att2_out, float* awe, float* gate, float* z);
 int mean_pixels(hipStream_t st, int rows, int P, int E, const float* enc, float* out);
 // dalpha[b,p] = enc[b,p,:] . dawe[b,:] + dalpha_in[b,p]
+// Pooled path (include/scnattn.h, scnattn_pool): encoder_out = fixed linear pooling of x [B][Q][E]
+struct PoolDesc {
+    int Q, qtap_max;
+    const int* tap_idx;     // [P][4]
+    const float* tap_w;     // [P][4]
+    const int* qtap_idx;    // [Q][qtap_max], -1 = unused
+    const float* qtap_w;    // [Q][qtap_max]
+    const float* col_w;     // [Q]: column sums of the pooling matrix / P (pixel mean of the pooled map)
+};
+int attn_context_pooled(hipStream_t st, int rows, int P, int E, const float* x, const PoolDesc& pool, const float* e,
+                        Slabs gpre, const float* bbeta, float* alpha_out, long alpha_ld, float* alpha_save,
+                        float* alphaq_save, float* awe, float* gate, float* z);
+int weighted_rows(hipStream_t st, int rows, int Q, int E, const float* x, const float* wts, float* out);
+int attn_softmax_bwd_pooled(hipStream_t st, int rows, int P, int A, const float* att1, const float* att2, const float* w,
+                            const float* alpha, const PoolDesc& pool, const float* dalphaq, const float* dalpha_in,
+                            long dalpha_in_ld, float* de, float* datt2, long datt2_ld);
+int pool_expand(hipStream_t st, int B, int P, int A, const PoolDesc& pool, const float* y, const float* bias, float* out);
+int pool_transpose(hipStream_t st, int B, int P, int A, const PoolDesc& pool, const float* in, float* out);
+int add_bcast_rows_w(hipStream_t st, int B, int Q, int E, const float* wts, const float* v, float* out);
 int attn_dalpha(hipStream_t st, int rows, int P, int E, const float* enc, const float* dawe,
                 const float* dalpha_in, long dalpha_in_ld, float* dalpha);
 // de = alpha*(dalpha - sum(alpha*dalpha));  datt2[b,a] = w[a] * sum_p de[b,p]*[att1+att2 > 0]

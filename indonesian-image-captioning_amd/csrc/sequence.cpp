@@ -87,23 +87,25 @@ struct Carver {
 
 struct Saved {
     float *att1, *qx, *qh, *ex, *emb_tm, *mean_enc, *Hs, *Cs, *att2_all, *alpha_tm, *awe_all, *gate_all, *z_all,
-        *pa_all, *ph_all, *gates_all, *tanhc_all, *Hd_bm, *rowmask;
+        *pa_all, *ph_all, *gates_all, *tanhc_all, *Hd_bm, *rowmask, *alphaq_tm;
 };
 
 constexpr long GEMM_WS_FLOATS = 8L << 20;   // 32 MiB of split-K partials for the big GEMMs
 
 struct FwdScratch {
-    float *WcatA, *WD, *slabA, *e, *slabC, *xcat, *slabD, *gws;
+    float *WcatA, *WD, *slabA, *e, *slabC, *xcat, *slabD, *gws, *y;
 };
 
 struct BwdScratch {
     float *WDb, *WaTz, *WcatT, *dHd_bm, *dhfc_tm, *dr_all, *dpx_all, *dcat_all, *dawe_all, *de_all, *dalpha, *dc,
-        *dqx_acc, *dqh_acc, *sDb, *sZ, *sH, *datt1, *dwpart, *dwtmp, *demb_tm, *dmean, *dh0, *mx_all, *gws, *present;
+        *dqx_acc, *dqh_acc, *sDb, *sZ, *sH, *datt1, *dwpart, *dwtmp, *demb_tm, *dmean, *dh0, *mx_all, *gws, *present,
+        *dalphaq, *dy;
 };
 
 inline size_t sz(long a, long b = 1, long c = 1, long d = 1) { return (size_t)a * b * c * d; }
 
-size_t carve_saved(const scnattn_dims& d, float* base, Saved& s) {
+// Q > 0: pooled path (encoder_out given as its un-pooled source map x [B][Q][E])
+size_t carve_saved(const scnattn_dims& d, int Q, float* base, Saved& s) {
     Carver c(base);
     const int B = d.B, P = d.P, E = d.E, A = d.A, D = d.D, F4 = 4 * d.F, T = d.T;
     s.att1 = d.has_att ? c.take(sz(B, P, A)) : nullptr;
@@ -125,12 +127,13 @@ size_t carve_saved(const scnattn_dims& d, float* base, Saved& s) {
     s.tanhc_all = c.take(sz(T, B, D));
     s.Hd_bm = c.take(sz(B, T, D));
     s.rowmask = c.take(sz(B, T));
+    s.alphaq_tm = (d.has_att && Q > 0) ? c.take(sz(T, B, Q)) : nullptr;
     return c.off * sizeof(float);
 }
 
 inline int ncatA(const scnattn_dims& d) { return d.has_att ? d.A + d.E + 4 * d.F : 4 * d.F; }
 
-size_t carve_fwd(const scnattn_dims& d, float* base, FwdScratch& s) {
+size_t carve_fwd(const scnattn_dims& d, int Q, float* base, FwdScratch& s) {
     Carver c(base);
     const int B = d.B, D = d.D, F = d.F, NA = ncatA(d);
     s.WcatA = c.take(sz(D, NA));
@@ -141,10 +144,11 @@ size_t carve_fwd(const scnattn_dims& d, float* base, FwdScratch& s) {
     s.xcat = c.take(sz(B, 4, 2 * F));
     s.slabD = c.take(sz(SCN_MAX_KSPLIT, 4, B, D));
     s.gws = c.take(GEMM_WS_FLOATS);
+    s.y = (d.has_att && Q > 0) ? c.take(sz(B, Q, d.A)) : nullptr;
     return c.off * sizeof(float);
 }
 
-size_t carve_bwd(const scnattn_dims& d, float* base, BwdScratch& s) {
+size_t carve_bwd(const scnattn_dims& d, int Q, float* base, BwdScratch& s) {
     Carver c(base);
     const int B = d.B, P = d.P, E = d.E, A = d.A, D = d.D, F = d.F, F4 = 4 * d.F, T = d.T, NC = ncatA(d);
     s.WDb = c.take(sz(4, D, 2 * F));
@@ -173,6 +177,8 @@ size_t carve_bwd(const scnattn_dims& d, float* base, BwdScratch& s) {
     s.mx_all = c.take(sz(T, B, F4));
     s.present = c.take(sz(d.V));
     s.gws = c.take(GEMM_WS_FLOATS);
+    s.dalphaq = (d.has_att && Q > 0) ? c.take(sz(B, Q)) : nullptr;
+    s.dy = (d.has_att && Q > 0) ? c.take(sz(B, Q, A)) : nullptr;
     return c.off * sizeof(float);
 }
 
@@ -192,6 +198,17 @@ int check_bt(const scnattn_dims* d, const int32_t* bt) {
         SCN_ARG(t == 0 || bt[t] <= bt[t - 1], "bt_host must be non-increasing (captions sorted by length)");
     }
     SCN_ARG(bt[0] == d->B, "bt_host[0] must equal B (every caption decodes at least one step)");
+    return 0;
+}
+
+int check_pool(const scnattn_dims* d, const scnattn_pool* p, PoolDesc& out) {
+    out = PoolDesc{0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (!p) return 0;
+    SCN_ARG(d->has_att, "scnattn_pool: only the attention decoders read encoder_out inside the loop");
+    SCN_ARG(p->Q > 0 && p->Q <= d->P && p->qtap_max > 0 && p->qtap_max <= 64, "scnattn_pool: bad Q / qtap_max");
+    SCN_ARG(p->tap_idx && p->tap_w && p->qtap_idx && p->qtap_w && p->col_w, "scnattn_pool: null table");
+    SCN_ARG(d->A % 4 == 0 && d->E % 4 == 0, "scnattn_pool: attention_dim and encoder_dim must be multiples of 4");
+    out = PoolDesc{p->Q, p->qtap_max, p->tap_idx, p->tap_w, p->qtap_idx, p->qtap_w, p->col_w};
     return 0;
 }
 
@@ -274,14 +291,16 @@ int run_chains(hipStream_t st, int kind, int B, Body&& body) {
 
 }  // namespace
 
-int seq_workspace(const scnattn_dims* d, size_t* saved_bytes, size_t* scratch_bytes) {
+int seq_workspace(const scnattn_dims* d, const scnattn_pool* pool, size_t* saved_bytes, size_t* scratch_bytes) {
     SCN_TRY(check_dims(d));
+    PoolDesc pd;
+    SCN_TRY(check_pool(d, pool, pd));
     Saved s;
     FwdScratch f;
     BwdScratch b;
-    const size_t sv = carve_saved(*d, nullptr, s);
-    const size_t fw = carve_fwd(*d, nullptr, f);
-    const size_t bw = carve_bwd(*d, nullptr, b);
+    const size_t sv = carve_saved(*d, pd.Q, nullptr, s);
+    const size_t fw = carve_fwd(*d, pd.Q, nullptr, f);
+    const size_t bw = carve_bwd(*d, pd.Q, nullptr, b);
     if (saved_bytes) *saved_bytes = sv;
     if (scratch_bytes) *scratch_bytes = fw > bw ? fw : bw;
     return 0;
@@ -289,18 +308,21 @@ int seq_workspace(const scnattn_dims* d, size_t* saved_bytes, size_t* scratch_by
 
 int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, const float* enc, const float* tags,
             const int64_t* caps, const int32_t* dl_dev, const int32_t* bt, const float* drop_mask, float* saved,
-            float* scratch, float* preds, float* alphas) {
+            float* scratch, float* preds, float* alphas, const scnattn_pool* pool) {
     SCN_TRY(check_dims(dp));
     SCN_TRY(check_bt(dp, bt));
     const scnattn_dims& d = *dp;
+    PoolDesc pd;
+    SCN_TRY(check_pool(dp, pool, pd));
+    const int Q = pd.Q;             // > 0: `enc` is the un-pooled map x [B][Q][E]
     SCN_ARG(w && enc && tags && caps && dl_dev && saved && scratch && preds, "seq_fwd: null argument");
     SCN_ARG(!d.has_att || alphas, "seq_fwd: alphas is NULL");
     const int B = d.B, P = d.P, E = d.E, A = d.A, D = d.D, F = d.F, F4 = 4 * F, M = d.M, T = d.T;
     const int NA = ncatA(d), colph = d.has_att ? A + E : 0;
     Saved s;
     FwdScratch f;
-    carve_saved(d, saved, s);
-    carve_fwd(d, scratch, f);
+    carve_saved(d, Q, saved, s);
+    carve_fwd(d, Q, scratch, f);
 
     // ---- weight re-layout: every per-step contraction streams a row-major [K][N] matrix ----------
     if (d.has_att) {
@@ -315,9 +337,15 @@ int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
     }
 
     // ---- time-invariant pieces -----------------------------------------------------------------
-    if (d.has_att)
+    if (d.has_att && Q > 0) {
+        // att1 = pool(x) . We^T + be = pool(x . We^T) + be: the projection runs on Q rows per image, not P
+        SCN_TRY(sgemm_ws(st, false, true, B * Q, A, E, 1.f, enc, E, w->attention_encoder_att_weight, E, 0.f, f.y, A,
+                      nullptr, nullptr, 1, 0, 0, 0, f.gws, GEMM_WS_FLOATS));
+        SCN_TRY(pool_expand(st, B, P, A, pd, f.y, w->attention_encoder_att_bias, s.att1));
+    } else if (d.has_att) {
         SCN_TRY(sgemm_ws(st, false, true, B * P, A, E, 1.f, enc, E, w->attention_encoder_att_weight, E, 0.f, s.att1, A,
                       w->attention_encoder_att_bias, nullptr, 1, 0, 0, 0, f.gws, GEMM_WS_FLOATS));
+    }
     SCN_TRY(sgemm_ws(st, false, false, B, F4, d.S, 1.f, tags, d.S, w->decode_step_weight_ib, F4, 0.f, s.qx, F4, nullptr,
                   nullptr, 1, 0, 0, 0, f.gws, GEMM_WS_FLOATS));
     SCN_TRY(sgemm_ws(st, false, false, B, F4, d.S, 1.f, tags, d.S, w->decode_step_weight_hb, F4, 0.f, s.qh, F4, nullptr,
@@ -325,7 +353,8 @@ int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
     SCN_TRY(gather_rows_tm(st, B, T, d.L, M, (const long long*)caps, w->embedding_weight, d.V, s.emb_tm));
     SCN_TRY(sgemm_ws(st, false, false, T * B, F4, M, 1.f, s.emb_tm, M, w->decode_step_weight_ia, F4, 0.f, s.ex, F4,
                   nullptr, nullptr, 1, 0, 0, 0, f.gws, GEMM_WS_FLOATS));
-    SCN_TRY(mean_pixels(st, B, P, E, enc, s.mean_enc));
+    if (Q > 0) SCN_TRY(weighted_rows(st, B, Q, E, enc, pd.col_w, s.mean_enc));
+    else SCN_TRY(mean_pixels(st, B, P, E, enc, s.mean_enc));
     SCN_TRY(sgemm_ws(st, false, true, B, D, E, 1.f, s.mean_enc, E, w->init_h_weight, E, 0.f, s.Hs, D, w->init_h_bias,
                   nullptr, 1, 0, 0, 0, f.gws, GEMM_WS_FLOATS));
     SCN_TRY(sgemm_ws(st, false, true, B, D, E, 1.f, s.mean_enc, E, w->init_c_weight, E, 0.f, s.Cs, D, w->init_c_bias,
@@ -335,7 +364,7 @@ int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
     const long BD = (long)B * D;
     hipEvent_t ev0 = prof_begin(st);
     SCN_TRY(run_chains(st, 0, B, [&](hipStream_t cs, int r0, int rmax) -> int {
-        const float* enc_c = enc + (long)r0 * P * E;
+        const float* enc_c = enc + (long)r0 * (Q > 0 ? Q : P) * E;
         const float* att1_c = d.has_att ? s.att1 + (long)r0 * P * A : nullptr;
         float* slabA = f.slabA + (long)r0 * NA;
         float* slabC = d.has_att ? f.slabC + (long)r0 * F4 : nullptr;
@@ -355,7 +384,17 @@ int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
             Slabs pz{nullptr, 0, 0, 0};
             if (d.has_att) {
                 float* alpha_out = alphas + (long)r0 * T * P + (long)t * P;
-                if (g_fuse_attn && attn_fused_ok(P, E, A, enc_c, att1_c)) {
+                if (Q > 0) {
+                    SCN_TRY(attn_scores(cs, bt_, P, A, att1_c, Slabs{slabA, ksA, (long)B * NA, NA},
+                                        w->attention_decoder_att_bias, w->attention_full_att_weight,
+                                        w->attention_full_att_bias, e_c, s.att2_all + rowT * A));
+                    hipEvent_t evc = g_profile >= 2 ? prof_begin(cs) : nullptr;
+                    SCN_TRY(attn_context_pooled(cs, bt_, P, E, enc_c, pd, e_c, Slabs{slabA + A, ksA, (long)B * NA, NA},
+                                                w->f_beta_bias, alpha_out, (long)T * P, s.alpha_tm + rowT * P,
+                                                s.alphaq_tm + rowT * Q, s.awe_all + rowT * E, s.gate_all + rowT * E,
+                                                s.z_all + rowT * E));
+                    prof_end(cs, evc, 2, 1);
+                } else if (g_fuse_attn && attn_fused_ok(P, E, A, enc_c, att1_c)) {
                     hipEvent_t evc = g_profile >= 2 ? prof_begin(cs) : nullptr;
                     SCN_TRY(attn_fused(cs, bt_, P, E, A, enc_c, att1_c, Slabs{slabA, ksA, (long)B * NA, NA},
                                        w->attention_decoder_att_bias, w->attention_full_att_weight,
@@ -403,10 +442,13 @@ int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
 int seq_bwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, const float* enc, const float* tags,
             const int64_t* caps, const int32_t* dl_dev, const int32_t* bt, const float* drop_mask, const float* saved,
             float* scratch, const float* dpreds, const float* dalphas, const scnattn_params* g, float* denc,
-            float* dtags) {
+            float* dtags, const scnattn_pool* pool) {
     SCN_TRY(check_dims(dp));
     SCN_TRY(check_bt(dp, bt));
     const scnattn_dims& d = *dp;
+    PoolDesc pd;
+    SCN_TRY(check_pool(dp, pool, pd));
+    const int Q = pd.Q;             // > 0: `enc` is x [B][Q][E] and `denc` receives d x [B][Q][E]
     SCN_ARG(w && g && enc && tags && caps && dl_dev && saved && scratch && dpreds, "seq_bwd: null argument");
     const int B = d.B, P = d.P, E = d.E, A = d.A, D = d.D, F = d.F, F4 = 4 * F, M = d.M, T = d.T, V = d.V;
     const int NC = ncatA(d);  // columns of the concatenated [dph | dgpre | datt2] operand
@@ -414,8 +456,8 @@ int seq_bwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
     const long BD = (long)B * D;
     Saved s;
     BwdScratch k;
-    carve_saved(d, const_cast<float*>(saved), s);
-    carve_bwd(d, scratch, k);
+    carve_saved(d, Q, const_cast<float*>(saved), s);
+    carve_bwd(d, Q, scratch, k);
 
     // ---- fc / dropout ----------------------------------------------------------------------------
     SCN_TRY(sgemm_ws(st, false, false, B * T, D, V, 1.f, dpreds, V, w->fc_weight, D, 0.f, k.dHd_bm, D, nullptr, nullptr, 1,
@@ -446,7 +488,7 @@ int seq_bwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
     // ---- reverse recurrence ----------------------------------------------------------------------
     hipEvent_t ev0 = prof_begin(st);
     SCN_TRY(run_chains(st, 1, B, [&](hipStream_t cs, int r0, int rmax) -> int {
-        const float* enc_c = enc + (long)r0 * P * E;
+        const float* enc_c = enc + (long)r0 * (Q > 0 ? Q : P) * E;
         const float* att1_c = d.has_att ? s.att1 + (long)r0 * P * A : nullptr;
         float* sDb = k.sDb + (long)r0 * 2 * F;
         float* sZ = d.has_att ? k.sZ + (long)r0 * E : nullptr;
@@ -481,10 +523,19 @@ int seq_bwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
                 float* dawe = k.dawe_all + rowT * E;
                 SCN_TRY(gate_bwd(cs, bt_, E, Slabs{sZ, ksZ, (long)B * E, E}, s.awe_all + rowT * E,
                                  s.gate_all + rowT * E, dawe, dcat + F4, NC));
-                SCN_TRY(attn_dalpha(cs, bt_, P, E, enc_c, dawe,
-                                    dalphas ? dalphas + (long)r0 * T * P + (long)t * P : nullptr, (long)T * P, dalpha));
-                SCN_TRY(attn_softmax_bwd(cs, bt_, P, A, att1_c, s.att2_all + rowT * A, w->attention_full_att_weight,
-                                         s.alpha_tm + rowT * P, dalpha, k.de_all + rowT * P, dcat + F4 + E, NC));
+                const float* din = dalphas ? dalphas + (long)r0 * T * P + (long)t * P : nullptr;
+                if (Q > 0) {
+                    // Q dot products per image against x, folded onto the P pooled pixels inside softmax_bwd
+                    float* dalphaq = k.dalphaq + (long)r0 * Q;
+                    SCN_TRY(attn_dalpha(cs, bt_, Q, E, enc_c, dawe, nullptr, 0, dalphaq));
+                    SCN_TRY(attn_softmax_bwd_pooled(cs, bt_, P, A, att1_c, s.att2_all + rowT * A,
+                                                    w->attention_full_att_weight, s.alpha_tm + rowT * P, pd, dalphaq, din,
+                                                    (long)T * P, k.de_all + rowT * P, dcat + F4 + E, NC));
+                } else {
+                    SCN_TRY(attn_dalpha(cs, bt_, P, E, enc_c, dawe, din, (long)T * P, dalpha));
+                    SCN_TRY(attn_softmax_bwd(cs, bt_, P, A, att1_c, s.att2_all + rowT * A, w->attention_full_att_weight,
+                                             s.alpha_tm + rowT * P, dalpha, k.de_all + rowT * P, dcat + F4 + E, NC));
+                }
             }
             ksH = pick(bt_, D, NC, 1);
             SCN_TRY(skinny_gemm(cs, bt_, D, NC, 1, dcat, NC, 0, k.WcatT, D, 0, sH, D, 0, BD, ksH));
@@ -556,9 +607,16 @@ int seq_bwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
         if (g->attention_full_att_weight)
             SCN_TRY(copy2d(st, 1, A, k.dwtmp, A + 1, g->attention_full_att_weight, A));
         if (g->attention_full_att_bias) SCN_TRY(copy2d(st, 1, 1, k.dwtmp + A, 1, g->attention_full_att_bias, 1));
-        if (g->attention_encoder_att_weight)
-            SCN_TRY(sgemm_ws(st, true, false, A, E, B * P, 1.f, k.datt1, A, enc, E, 0.f, g->attention_encoder_att_weight,
-                          E, nullptr, nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
+        if (Q > 0 && (g->attention_encoder_att_weight || denc))
+            SCN_TRY(pool_transpose(st, B, P, A, pd, k.datt1, k.dy));      // d y = pool^T (d att1): [B*Q][A]
+        if (g->attention_encoder_att_weight) {
+            if (Q > 0)
+                SCN_TRY(sgemm_ws(st, true, false, A, E, B * Q, 1.f, k.dy, A, enc, E, 0.f, g->attention_encoder_att_weight,
+                              E, nullptr, nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
+            else
+                SCN_TRY(sgemm_ws(st, true, false, A, E, B * P, 1.f, k.datt1, A, enc, E, 0.f,
+                              g->attention_encoder_att_weight, E, nullptr, nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
+        }
         if (g->attention_encoder_att_bias)
             SCN_TRY(colsum(st, B * P, A, k.datt1, A, g->attention_encoder_att_bias, 0.f));
     }
@@ -574,7 +632,18 @@ int seq_bwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
     if (g->init_c_bias) SCN_TRY(colsum(st, B, D, k.dc, D, g->init_c_bias, 0.f));
 
     // ---- d loss / d encoder_out (only when the encoder is fine-tuned) -------------------------------
-    if (denc) {
+    if (denc && Q > 0) {
+        // d x = d y . We  +  sum_t alphaq_t (x) dawe_t  +  col_w (x) d mean      (all on the Q source pixels)
+        SCN_TRY(sgemm_ws(st, false, false, B * Q, E, A, 1.f, k.dy, A, w->attention_encoder_att_weight, E, 0.f, denc, E,
+                      nullptr, nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
+        SCN_TRY(sgemm_ws(st, true, false, Q, E, T, 1.f, s.alphaq_tm, (long)B * Q, k.dawe_all, (long)B * E, 1.f, denc, E,
+                      nullptr, nullptr, B, Q, E, (long)Q * E, k.gws, GEMM_WS_FLOATS));
+        SCN_TRY(sgemm_ws(st, false, false, B, E, D, 1.f, k.dh0, D, w->init_h_weight, E, 0.f, k.dmean, E, nullptr, nullptr,
+                      1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
+        SCN_TRY(sgemm_ws(st, false, false, B, E, D, 1.f, k.dc, D, w->init_c_weight, E, 1.f, k.dmean, E, nullptr, nullptr,
+                      1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
+        SCN_TRY(add_bcast_rows_w(st, B, Q, E, pd.col_w, k.dmean, denc));
+    } else if (denc) {
         if (d.has_att) {
             SCN_TRY(sgemm_ws(st, false, false, B * P, E, A, 1.f, k.datt1, A, w->attention_encoder_att_weight, E, 0.f,
                           denc, E, nullptr, nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));

@@ -30,6 +30,23 @@ def sort_by_length(encoder_out, encoded_captions, caption_lengths, sort_ind=None
     return enc, encoded_captions, decode_lengths, (lens - 1).to(torch.int32), sort_ind
 
 
+USE_PREPOOL = True     # set False to force the dense (B, P, E) path even when the encoder attached its source map
+
+
+def attached_prepool(encoder_out):
+    """The un-pooled trunk output (B, h, w, E) that `EncoderCaption.forward` attaches to the pooled tensor it
+    returns, if `encoder_out` is still that very tensor, unmodified (same object, same version counter)."""
+    if not USE_PREPOOL or encoder_out is None:
+        return None
+    tag = getattr(encoder_out, "_scn_prepool", None)
+    if tag is None:
+        return None
+    pre, version = tag
+    if version != encoder_out._version or pre.shape[0] != encoder_out.shape[0] or pre.shape[-1] != encoder_out.shape[-1]:
+        return None
+    return pre
+
+
 def active_rows(decode_lengths):
     return [sum(l > t for l in decode_lengths) for t in range(max(decode_lengths))]
 

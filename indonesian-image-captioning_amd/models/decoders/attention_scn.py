@@ -59,17 +59,34 @@ class AttentionSCN(nn.Module):
         c = SF.linear(mean_encoder_out, self.init_c.weight, self.init_c.bias)
         return h, c
 
-    def forward(self, encoder_out, semantic_input, encoded_captions, caption_lengths, sort_ind=None):
+    def forward(self, encoder_out, semantic_input, encoded_captions, caption_lengths, sort_ind=None, prepool=None,
+                pool_size=14):
+        """Reference signature (attention_scn.py:95) plus optional extras.  `prepool`: the encoder trunk's map
+        (B, h, w, E) of which `encoder_out` is the AdaptiveAvgPool2d(pool_size) (models/encoders/caption.py:41-43);
+        given it -- explicitly, or attached by this build's EncoderCaption to the tensor it returned -- the
+        attention runs on the h*w source pixels and the pooled map is not read (same numbers by linearity,
+        SURVEY 8d); `encoder_out` may then be None."""
+        pre = prepool if prepool is not None else _common.attached_prepool(encoder_out)
+        pool = None
+        if pre is not None and pre.is_cuda and pre.dim() == 4:
+            out_hw = tuple(encoder_out.shape[1:3]) if encoder_out is not None else (pool_size, pool_size)
+            try:
+                pool = SF.pool_taps(pre.shape[1], pre.shape[2], out_hw[0], out_hw[1], pre.device)
+            except ValueError:
+                pool = None                      # not an up-sampling pool: dense path
+        if pool is None and encoder_out is None:
+            raise RuntimeError("AttentionSCN.forward: encoder_out is None and no usable prepool map was given")
         enc, caps, decode_lengths, dl_dev, sort_ind = _common.sort_by_length(
-            encoder_out, encoded_captions, caption_lengths, sort_ind)
-        B, P, E = enc.shape
+            pre if pool is not None else encoder_out, encoded_captions, caption_lengths, sort_ind)
+        B, E = enc.shape[0], enc.shape[2]
+        P = pool.P if pool is not None else enc.shape[1]
         T = max(decode_lengths)
         dims = (B, P, E, self.attention_dim, self.decoder_dim, self.factored_dim, self.embed_dim,
                 self.semantic_dim, self.vocab_size, T, caps.size(1), 1)
         mask = _common.make_drop_mask(self, B, T, self.decoder_dim, enc.device)
         weights = _collect_weights(self)
         predictions, alphas = SF.decoder_sequence(dims, _common.active_rows(decode_lengths), enc, semantic_input,
-                                                  caps, dl_dev, mask, weights)
+                                                  caps, dl_dev, mask, weights, pool)
         return predictions, caps, decode_lengths, alphas, sort_ind
 
     def sample(self, beam_size, word_map, encoder_out, tag_out):

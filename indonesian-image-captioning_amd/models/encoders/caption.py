@@ -27,7 +27,11 @@ class EncoderCaption(nn.Module):
             self.resnet.load_state_dict({k: v for k, v in sd.items() if not k.startswith("fc.")}, strict=False)
         self.fine_tune()
 
-    def forward(self, images):
+    def forward(self, images, pooled=True):
+        """(B, 3, H, W) -> (B, enc_image_size, enc_image_size, 2048) as the reference (:34-44).  The returned
+        tensor carries the un-pooled trunk map as `_scn_prepool` so that this build's attention decoders can
+        work on its 8x8 source pixels (models/decoders/_common.py::attached_prepool); `pooled=False` returns
+        that (B, h, w, 2048) map itself and skips the pooling."""
         if self.channels_last and images.is_cuda:
             images = images.contiguous(memory_format=torch.channels_last)
         if images.is_cuda and self.training:
@@ -37,7 +41,13 @@ class EncoderCaption(nn.Module):
             if flat is not None:
                 flat.add_(1)     # all BatchNorm num_batches_tracked counters, one launch
         out = self.resnet(images)
-        return SF.pool_permute(out, self.enc_image_size)
+        pre = out.permute(0, 2, 3, 1)             # a contiguous (B, h, w, C) view when the trunk is channels-last
+        if not pooled:
+            return pre
+        y = SF.pool_permute(out, self.enc_image_size)
+        if y.is_cuda:
+            y._scn_prepool = (pre, y._version)
+        return y
 
     def fine_tune(self, fine_tune=True):
         for p in self.resnet.parameters():

@@ -40,14 +40,20 @@ class Params(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in PARAM_FIELDS]
 
 
+class Pool(C.Structure):      # scnattn_pool
+    _fields_ = [("Q", C.c_int), ("qtap_max", C.c_int), ("tap_idx", C.c_void_p), ("tap_w", C.c_void_p),
+                ("qtap_idx", C.c_void_p), ("qtap_w", C.c_void_p), ("col_w", C.c_void_p)]
+
+
 _SIGS = {
     "scnattn_version": ([], i32),
     "scnattn_set_option": ([C.c_char_p, i32], i32),
     "scnattn_profile_collect": ([C.POINTER(C.c_double)], i32),
-    "scnattn_seq_workspace": ([C.POINTER(Dims), C.POINTER(sz), C.POINTER(sz)], i32),
-    "scnattn_seq_fwd": ([vp, C.POINTER(Dims), C.POINTER(Params), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp], i32),
+    "scnattn_seq_workspace": ([C.POINTER(Dims), C.POINTER(Pool), C.POINTER(sz), C.POINTER(sz)], i32),
+    "scnattn_seq_fwd": ([vp, C.POINTER(Dims), C.POINTER(Params), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                         C.POINTER(Pool)], i32),
     "scnattn_seq_bwd": ([vp, C.POINTER(Dims), C.POINTER(Params), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
-                         C.POINTER(Params), vp, vp], i32),
+                         C.POINTER(Params), vp, vp, C.POINTER(Pool)], i32),
     "scnattn_sgemm": ([vp, i32, i32, i32, i32, i32, f32, vp, i64, vp, i64, f32, vp, i64, vp, vp, i32, i64, i64, i64], i32),
     "scnattn_skinny_gemm": ([vp, i32, i32, i32, i32, vp, i64, i64, vp, i64, i64, vp, i64, i64, i64, i32,
                              C.POINTER(i32)], i32),

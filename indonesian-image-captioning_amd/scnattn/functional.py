@@ -13,7 +13,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import Dims, Params, PARAM_FIELDS, call, ptr, stream_of, f32c, require_cuda
+from ._lib import Pool, Dims, Params, PARAM_FIELDS, call, ptr, stream_of, f32c, require_cuda
 
 
 # ----------------------------------------------------------------------------------------------
@@ -62,6 +62,61 @@ def _params_struct(tensors):
     return p
 
 
+class PoolTaps:
+    """`encoder_out = AdaptiveAvgPool2d(out)(x)` (models/encoders/caption.py:20,41) as tap tables: pooled pixel p
+    averages <= 4 source pixels (the pool up-samples: 8x8 -> 14x14 windows are 1 or 2 wide), `matrix()` is the
+    dense (P, Q) pooling matrix they encode.  Device tensors + the scnattn_pool struct the C ABI takes."""
+
+    def __init__(self, in_h, in_w, out_h, out_w, device):
+        def windows(n_in, n_out):     # torch's adaptive pooling windows: [floor(i*n/o), ceil((i+1)*n/o))
+            return [(i * n_in // n_out, -(-(i + 1) * n_in // n_out)) for i in range(n_out)]
+        rows, cols = windows(in_h, out_h), windows(in_w, out_w)
+        P, Q = out_h * out_w, in_h * in_w
+        tap_idx = torch.zeros(P, 4, dtype=torch.int32)
+        tap_w = torch.zeros(P, 4, dtype=torch.float32)
+        per_q = [[] for _ in range(Q)]
+        for i, (r0, r1) in enumerate(rows):
+            for j, (c0, c1) in enumerate(cols):
+                p = i * out_w + j
+                src = [(r, c) for r in range(r0, r1) for c in range(c0, c1)]
+                if len(src) > 4:
+                    raise ValueError("pooling window of %d pixels: the pooled path handles up-sampling pools "
+                                     "(windows of at most 2x2)" % len(src))
+                for k, (r, c) in enumerate(src):
+                    q = r * in_w + c
+                    tap_idx[p, k] = q
+                    tap_w[p, k] = 1.0 / len(src)
+                    per_q[q].append((p, 1.0 / len(src)))
+        qmax = max(len(l) for l in per_q)
+        qtap_idx = torch.full((Q, qmax), -1, dtype=torch.int32)
+        qtap_w = torch.zeros(Q, qmax, dtype=torch.float32)
+        for q, l in enumerate(per_q):
+            for k, (p, wv) in enumerate(l):
+                qtap_idx[q, k] = p
+                qtap_w[q, k] = wv
+        col_w = (qtap_w.double().sum(dim=1) / P).float()
+        self.P, self.Q, self.qmax, self.shape = P, Q, qmax, (in_h, in_w, out_h, out_w)
+        self.tap_idx, self.tap_w = tap_idx.to(device), tap_w.to(device)
+        self.qtap_idx, self.qtap_w, self.col_w = qtap_idx.to(device), qtap_w.to(device), col_w.to(device)
+        self.cstruct = Pool(Q, qmax, self.tap_idx.data_ptr(), self.tap_w.data_ptr(), self.qtap_idx.data_ptr(),
+                            self.qtap_w.data_ptr(), self.col_w.data_ptr())
+
+    def matrix(self):
+        m = torch.zeros(self.P, self.Q, dtype=torch.float32, device=self.tap_w.device)
+        m.scatter_add_(1, self.tap_idx.long(), self.tap_w)
+        return m
+
+
+_pool_cache = {}
+
+
+def pool_taps(in_h, in_w, out_h, out_w, device):
+    key = (in_h, in_w, out_h, out_w, str(device))
+    if key not in _pool_cache:
+        _pool_cache[key] = PoolTaps(in_h, in_w, out_h, out_w, device)
+    return _pool_cache[key]
+
+
 _POISON = False     # tests: NaN-fill workspaces that are claimed to be fully overwritten
 
 
@@ -77,8 +132,9 @@ def _workspace(nfloats, dev, fully_written):
 class _DecoderSeq(torch.autograd.Function):
     @staticmethod
     def forward(ctx, meta, enc, tags, caps, dl_dev, drop_mask, *weights):
-        dims_t, bt_host = meta
+        dims_t, bt_host, pool = meta       # pool: PoolTaps or None; with it `enc` is the un-pooled map (B, Q, E)
         d = Dims(*dims_t)
+        cpool = None if pool is None else C.byref(pool.cstruct)
         require_cuda(enc, tags, caps, dl_dev, *weights)
         dev = enc.device
         enc, tags = f32c(enc), f32c(tags)
@@ -86,7 +142,7 @@ class _DecoderSeq(torch.autograd.Function):
         weights = tuple(None if w is None else f32c(w.detach()) for w in weights)
         drop_mask = f32c(drop_mask)
         sv, sc = C.c_size_t(), C.c_size_t()
-        call("scnattn_seq_workspace", C.byref(d), C.byref(sv), C.byref(sc))
+        call("scnattn_seq_workspace", C.byref(d), cpool, C.byref(sv), C.byref(sc))
         # Rows (t, b >= b_t) of the time-major buffers are never written by the kernels but are read by the
         # post-loop GEMMs (and returned, for alphas), so they must be zero -- unless every row decodes at every
         # step (fixed-length captions), where each element is written before it is read and the 120 MB fill is
@@ -99,8 +155,8 @@ class _DecoderSeq(torch.autograd.Function):
         bt = (C.c_int32 * d.T)(*bt_host)
         w = _params_struct(weights)
         call("scnattn_seq_fwd", stream_of(enc), C.byref(d), C.byref(w), ptr(enc), ptr(tags), ptr(caps), ptr(dl_dev),
-             C.cast(bt, C.c_void_p), ptr(drop_mask), ptr(saved), ptr(scratch), ptr(preds), ptr(alphas))
-        ctx.meta = (dims_t, tuple(bt_host), sc.value)
+             C.cast(bt, C.c_void_p), ptr(drop_mask), ptr(saved), ptr(scratch), ptr(preds), ptr(alphas), cpool)
+        ctx.meta = (dims_t, tuple(bt_host), sc.value, pool)
         ctx.save_for_backward(enc, tags, caps, dl_dev, drop_mask, saved, *[x for x in weights if x is not None])
         ctx.wmask = tuple(x is not None for x in weights)
         if alphas is None:
@@ -110,8 +166,9 @@ class _DecoderSeq(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dpreds, dalphas):
-        dims_t, bt_host, scratch_bytes = ctx.meta
+        dims_t, bt_host, scratch_bytes, pool = ctx.meta
         d = Dims(*dims_t)
+        cpool = None if pool is None else C.byref(pool.cstruct)
         enc, tags, caps, dl_dev, drop_mask, saved, *wl = ctx.saved_tensors
         it = iter(wl)
         weights = tuple(next(it) if m else None for m in ctx.wmask)
@@ -134,14 +191,17 @@ class _DecoderSeq(torch.autograd.Function):
         w, g = _params_struct(weights), _params_struct(grads)
         call("scnattn_seq_bwd", stream_of(enc), C.byref(d), C.byref(w), ptr(enc), ptr(tags), ptr(caps), ptr(dl_dev),
              C.cast(bt, C.c_void_p), ptr(drop_mask), ptr(saved), ptr(scratch), ptr(dpreds), ptr(dalphas),
-             C.byref(g), ptr(denc), ptr(dtags))
+             C.byref(g), ptr(denc), ptr(dtags), cpool)
         return (None, denc, dtags, None, None, None, *grads)
 
 
-def decoder_sequence(dims, bt_host, enc, tags, caps, dl_dev, drop_mask, weights):
+def decoder_sequence(dims, bt_host, enc, tags, caps, dl_dev, drop_mask, weights, pool=None):
     """dims: 12-tuple in scnattn_dims order; weights: tensors in PARAM_FIELDS order (None = absent).
-    Returns (predictions (B,T,V), alphas (B,T,P) or None)."""
-    preds, alphas = _DecoderSeq.apply((tuple(dims), tuple(bt_host)), enc, tags, caps, dl_dev, drop_mask, *weights)
+    pool: PoolTaps -- then `enc` is the un-pooled feature map (B, Q, E) and the pooled encoder_out is never
+    built.  Returns (predictions (B,T,V), alphas (B,T,P) or None)."""
+    if pool is not None and (enc.dim() != 3 or enc.shape[1] != pool.Q or dims[1] != pool.P):
+        raise RuntimeError("decoder_sequence: the un-pooled map must be (B, %d, E) for this pool" % pool.Q)
+    preds, alphas = _DecoderSeq.apply((tuple(dims), tuple(bt_host), pool), enc, tags, caps, dl_dev, drop_mask, *weights)
     return preds, (alphas if dims[-1] else None)
 
 

@@ -60,11 +60,12 @@ def build_decoder(kind, cfg):
 class TrainStep:
     def __init__(self, kind="attention_scn", fine_tune_encoder=True, device="cuda", seed=1234, encoder=True,
                  bucket_mb=32, graph_encoder=False, tagger=False, force_reduce=False, encoder_dtype="f32",
-                 fused_loss=True, **overrides):
+                 fused_loss=True, pooled_attention=True, **overrides):
         self.cfg = dict(DEFAULTS)
         self.cfg.update(overrides)
         self.kind = kind
         self.fused_loss = fused_loss
+        self.pooled_attention = pooled_attention   # attention on the trunk's 8x8 map instead of its 14x14 pooling
         # "bf16": the ResNet trunk runs under bf16 autocast (MIOpen bf16 MFMA convolutions, bf16 feature maps
         # through the fused BatchNorm kernels, fp32 master weights/statistics); the decoder stays fp32.
         # This is BASELINE config 5's mixed-precision flavour, NOT the headline fp32 metric.
@@ -128,16 +129,22 @@ class TrainStep:
             loss = loss + self.cfg["alpha_c"] * ((1. - alphas.sum(dim=1)) ** 2).mean()
         return loss
 
-    def step(self, imgs, tags, caps, caplens, encoder_out=None):
+    def step(self, imgs, tags, caps, caplens, encoder_out=None, prepool=None):
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.encoder_bf16):
             if self.encoder is not None:
-                encoder_out = self.encoder_call(imgs)
+                if self.kind == "attention_scn" and self.pooled_attention and self.encoder_call is self.encoder:
+                    prepool = self.encoder(imgs, pooled=False)     # the decoder works on the 8x8 source map
+                    encoder_out = None
+                else:
+                    encoder_out = self.encoder_call(imgs)
             if self.tagger is not None:
                 tags = self.tagger(imgs)
         if self.tagger is not None:
             tags = tags.float()
         if self.kind == "attention_scn":
-            scores, caps_sorted, decode_lengths, alphas, sort_ind = self.decoder(encoder_out, tags, caps, caplens)
+            scores, caps_sorted, decode_lengths, alphas, sort_ind = self.decoder(
+                encoder_out, tags, caps, caplens, prepool=prepool,
+                pool_size=self.encoder.enc_image_size if self.encoder is not None else 14)
         elif self.kind == "pure_scn":
             scores, caps_sorted, decode_lengths, sort_ind = self.decoder(encoder_out, tags, caps, caplens)
             alphas = None

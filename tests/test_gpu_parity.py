@@ -1003,3 +1003,79 @@ def test_full_length_batch_never_reads_unwritten_workspace(dev, kind):
     out2 = m(e2, tags, caps[rev], caplens, sort_ind=rev)           # Q1: tags are indexed un-permuted by sorted position
     assert torch.equal(out2[1], caps) and out2[-1] is rev
     _ok(out2[0], runs[0][0], 1e-6, "predictions under an explicit permutation")
+
+
+@pytest.mark.parametrize("B,lens,hin", [(6, [8, 8, 6, 5, 3, 2], 8), (4, [5, 5, 5, 5], 8), (3, [7, 4, 4], 7)])
+def test_pooled_attention_path_equals_dense_path(dev, B, lens, hin):
+    """Attention on the trunk's un-pooled map (scnattn_pool: att1 = pool(x.We^T)+be, context / d alpha over the Q
+    source pixels, d x produced directly) against the dense path fed with the materialised AdaptiveAvgPool2d(14)
+    output: predictions, alphas, every parameter gradient, and d x against the dense d encoder_out pushed back
+    through the pool.  Ragged lengths, an explicit permutation (unsorted batch) and a non-square-friendly 7x7 map."""
+    from models.decoders.attention_scn import AttentionSCN
+    torch.manual_seed(5 + B)
+    V, L, E = 50, 10, 64
+    m = AttentionSCN(32, 24, 32, 40, 12, V, encoder_dim=E, dropout=0.0).to(dev).train()
+    x = torch.rand(B, hin, hin, E, device=dev)
+    tags = torch.rand(B, 12, device=dev)
+    caps = torch.randint(1, V - 3, (B, L), device=dev)
+    order = torch.randperm(B)                     # lengths not sorted: the decoder must permute x itself
+    caplens = (torch.tensor(lens)[order] + 1).unsqueeze(1).to(dev)
+    w = torch.rand(B, L - 1, V, device=dev)
+    results = []
+    for pooled in (False, True):
+        m.zero_grad(set_to_none=True)
+        xx = x.clone().requires_grad_(True)
+        enc = torch.nn.functional.adaptive_avg_pool2d(xx.permute(0, 3, 1, 2), 14).permute(0, 2, 3, 1)
+        if pooled:
+            out = m(None, tags, caps, caplens, prepool=xx, pool_size=14)
+        else:
+            out = m(enc, tags, caps, caplens)
+        T = out[0].shape[1]
+        loss = (out[0] * w[:, :T]).sum() + (out[3] ** 2).sum()
+        loss.backward()
+        results.append((out[0].detach(), out[3].detach(), xx.grad.clone(),
+                        {k: p.grad.clone() for k, p in m.named_parameters()}, out[4]))
+    (p0, a0, dx0, g0, s0), (p1, a1, dx1, g1, s1) = results
+    assert torch.equal(s0, s1)
+    _ok(p1, p0, 1e-5, "predictions")
+    _ok(a1, a0, 1e-5, "alphas")
+    assert rel_l2(dx1, dx0) <= 2e-5, "d x: %.3e" % rel_l2(dx1, dx0)
+    for k in g0:
+        if k.endswith("full_att.bias"):
+            assert (g1[k] - g0[k]).abs().max().item() <= 1e-4
+            continue
+        assert rel_l2(g1[k], g0[k]) <= 5e-5, "%s: %.3e" % (k, rel_l2(g1[k], g0[k]))
+
+
+def test_encoder_attaches_prepool_and_decoder_uses_it(dev):
+    """EncoderCaption tags the pooled tensor it returns with the trunk map; the decoder then takes the pooled
+    path on its own (the reference's train loop passes the tensor through untouched), falls back to the dense
+    path when the tensor was modified in place, and both give the same numbers."""
+    from models.decoders import _common
+    from models.decoders.attention_scn import AttentionSCN
+    from models.encoders.caption import EncoderCaption
+    from scnattn.resnet import resnet152_trunk
+    torch.manual_seed(2)
+    encm = EncoderCaption(channels_last=True)
+    encm.resnet = resnet152_trunk(depths=(1, 1, 1, 1))
+    encm = encm.to(dev).eval()
+    dec = AttentionSCN(32, 24, 32, 40, 12, 40, dropout=0.0).to(dev).train()
+    imgs = torch.randn(2, 3, 64, 64, device=dev)
+    tags = torch.rand(2, 12, device=dev)
+    caps = torch.randint(1, 36, (2, 7), device=dev)
+    caplens = torch.tensor([[7], [5]], device=dev)
+    with torch.no_grad():
+        y = encm(imgs)
+        assert y.shape == (2, 14, 14, 2048) and _common.attached_prepool(y) is not None
+        assert _common.attached_prepool(y).shape == (2, 2, 2, 2048)
+        assert tuple(encm(imgs, pooled=False).shape) == (2, 2, 2, 2048)
+        auto = dec(y, tags, caps, caplens)
+        _common.USE_PREPOOL = False
+        try:
+            dense = dec(y, tags, caps, caplens)
+        finally:
+            _common.USE_PREPOOL = True
+        _ok(auto[0], dense[0], 1e-5, "auto-pooled vs dense")
+        y.mul_(1.0)                                   # in-place touch: version counter moves, tag is void
+        assert _common.attached_prepool(y) is None
+        assert _common.attached_prepool(y * 1.0) is None

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(h, name), "libscnattn.so does not export " + name
     assert set(L.EXPORTS) <= declared | {"scnattn_last_error"}
-    assert h.scnattn_version() == 100
+    assert h.scnattn_version() == 101
 
 
 def test_invalid_arguments_return_codes_and_messages():
@@ -39,10 +39,10 @@ def test_invalid_arguments_return_codes_and_messages():
     assert b"unknown option" in h.scnattn_last_error()
     d = L.Dims(0, 196, 2048, 512, 512, 512, 512, 1000, 100, 5, 7, 1)   # B = 0
     sv, sc = C.c_size_t(), C.c_size_t()
-    assert h.scnattn_seq_workspace(C.byref(d), C.byref(sv), C.byref(sc)) == -1
+    assert h.scnattn_seq_workspace(C.byref(d), None, C.byref(sv), C.byref(sc)) == -1
     assert b"positive" in h.scnattn_last_error()
     d = L.Dims(32, 196, 2048, 512, 512, 512, 512, 1000, 10000, 51, 52, 1)
-    assert h.scnattn_seq_workspace(C.byref(d), C.byref(sv), C.byref(sc)) == 0
+    assert h.scnattn_seq_workspace(C.byref(d), None, C.byref(sv), C.byref(sc)) == 0
     assert sv.value > 0 and sc.value > 0 and sv.value % 256 == 0
     # null operands are rejected before any launch
     assert h.scnattn_sgemm(None, 0, 0, 4, 4, 4, 1.0, None, 4, None, 4, 0.0, None, 4, None, None, 1, 0, 0, 0) == -1
@@ -289,3 +289,27 @@ def test_checkpoint_roundtrip_keeps_reference_layout_and_flat_aliasing(tmp_path)
     assert torch.equal(fresh.fc.weight.cpu(), dec.fc.weight)
     with pytest.raises(ValueError, match="model type not found"):
         load_decoder("nope", {}, 30)
+
+
+@pytest.mark.parametrize("hin,hout", [(8, 14), (7, 14), (14, 14), (5, 9)])
+def test_pool_taps_encode_adaptive_avg_pool(hin, hout):
+    """scnattn.functional.PoolTaps (the tables behind scnattn_pool) reproduce AdaptiveAvgPool2d + permute of
+    models/encoders/caption.py:41-43 exactly, their transpose lists are consistent, and pools that are not
+    up-sampling (windows wider than 2) are refused."""
+    from scnattn import functional as SF
+    pt = SF.PoolTaps(hin, hin, hout, hout, "cpu")
+    x = torch.randn(3, 6, hin, hin, dtype=torch.float64)
+    ref = torch.nn.functional.adaptive_avg_pool2d(x, hout).permute(0, 2, 3, 1).reshape(3, hout * hout, 6)
+    m = pt.matrix().double()
+    got = m @ x.permute(0, 2, 3, 1).reshape(3, hin * hin, 6)
+    assert (got - ref).abs().max().item() <= 1e-12
+    assert torch.allclose(m.sum(dim=1), torch.ones(hout * hout, dtype=torch.float64))
+    mt = torch.zeros(pt.Q, pt.P, dtype=torch.float64)
+    for q in range(pt.Q):
+        for k in range(pt.qmax):
+            if pt.qtap_idx[q, k] >= 0:
+                mt[q, pt.qtap_idx[q, k]] += pt.qtap_w[q, k]
+    assert torch.equal(mt, m.t())
+    assert torch.allclose(pt.col_w.double(), m.sum(dim=0) / pt.P)
+    with pytest.raises(ValueError):
+        SF.PoolTaps(14, 14, 4, 4, "cpu")
