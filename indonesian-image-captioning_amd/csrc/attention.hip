@@ -167,10 +167,8 @@ __global__ __launch_bounds__(512) void attn_context_kernel(int rows, int P, int 
         float* aq = alph + P;
         for (int q = tid; q < pq.Q; q += 512) {
             float a = 0.f;
-            for (int k = 0; k < pq.qtap_max; ++k) {
-                const int pi = pq.qtap_idx[q * pq.qtap_max + k];
-                if (pi >= 0) a = fmaf(pq.qtap_w[q * pq.qtap_max + k], alph[pi], a);
-            }
+            for (int k = 0; k < pq.qtap_max; ++k)      // unused taps carry weight 0: clamp the index, no branch
+                a = fmaf(pq.qtap_w[q * pq.qtap_max + k], alph[max(pq.qtap_idx[q * pq.qtap_max + k], 0)], a);
             aq[q] = a;
             if (blockIdx.x == 0 && pq.alphaq_save) pq.alphaq_save[(long)b * pq.Q + q] = a;
         }
@@ -358,34 +356,36 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(int rows, int P, int E,
 }
 
 // ------------------------------------------------------------------------------------------------
-template <bool VEC, int U>
+template <bool VEC, int U, int RW>
 __global__ __launch_bounds__(256) void attn_dalpha_kernel(int rows, int P, int E, const float* __restrict__ enc,
                                                           const float* __restrict__ dawe,
                                                           const float* __restrict__ dalpha_in, long din_ld,
                                                           float* __restrict__ dalpha) {
+    // RW rows per wave, 4 waves: 4*RW rows per workgroup.  RW = 4 for the 196 pooled pixels; RW = 2 with
+    // U = 8 for the 64 source pixels of the pooled path (twice the workgroups, a 2048-wide row in one batch).
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int E4 = (E + 3) & ~3;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y, p0 = blockIdx.x * PC;
-    const float* rowp[4];
-    bool ok[4];
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int b = blockIdx.y, p0 = blockIdx.x * (4 * RW);
+    const float* rowp[RW];
+    bool ok[RW];
+    float acc[RW];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int p = p0 + wave * 4 + j;
+    for (int j = 0; j < RW; ++j) {
+        const int p = p0 + wave * RW + j;
         ok[j] = p < P;
+        acc[j] = 0.f;
         rowp[j] = enc + ((long)b * P + (ok[j] ? p : P - 1)) * E;
     }
     if (VEC) {
-        // U column chunks x 4 rows = 4U x 16 B loads in flight per lane (U = 4 for E >= 1024: two batches
-        // cover a 2048-wide row instead of four); the first batch is issued before the LDS staging of dawe
-        // (it does not depend on it)
-        f32x4 v[U][4];
+        // U column chunks x RW rows = RW*U x 16 B loads in flight per lane; the first batch is issued before
+        // the LDS staging of dawe (it does not depend on it)
+        f32x4 v[U][RW];
         const int cmax = E - 4;
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[u][j] = *reinterpret_cast<const f32x4*>(rowp[j] + min(lane * 4 + 256 * u, cmax));
+            for (int j = 0; j < RW; ++j) v[u][j] = *reinterpret_cast<const f32x4*>(rowp[j] + min(lane * 4 + 256 * u, cmax));
         for (int c = tid; c < E4; c += 256) sm[c] = c < E ? dawe[(long)b * E + c] : 0.f;
         __syncthreads();
         for (int c0 = lane * 4;;) {
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void attn_dalpha_kernel(int rows, int P, int E
                 if (c < E) {
                     const f32x4 d = *reinterpret_cast<const f32x4*>(sm + c);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < RW; ++j)
 #pragma unroll
                         for (int k = 0; k < 4; ++k) acc[j] = fmaf(v[u][j][k], d[k], acc[j]);
                 }
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void attn_dalpha_kernel(int rows, int P, int E
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[u][j] = *reinterpret_cast<const f32x4*>(rowp[j] + min(c0 + 256 * u, cmax));
+                for (int j = 0; j < RW; ++j) v[u][j] = *reinterpret_cast<const f32x4*>(rowp[j] + min(c0 + 256 * u, cmax));
         }
     } else {
         for (int c = tid; c < E4; c += 256) sm[c] = c < E ? dawe[(long)b * E + c] : 0.f;
@@ -413,13 +413,13 @@ __global__ __launch_bounds__(256) void attn_dalpha_kernel(int rows, int P, int E
         for (int c = lane; c < E; c += 64) {
             const float d = sm[c];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = fmaf(rowp[j][c], d, acc[j]);
+            for (int j = 0; j < RW; ++j) acc[j] = fmaf(rowp[j][c], d, acc[j]);
         }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < RW; ++j) {
         const float s = wave_sum(acc[j]);
-        const int p = p0 + wave * 4 + j;
+        const int p = p0 + wave * RW + j;
         if (lane == 0 && ok[j]) dalpha[(long)b * P + p] = s + (dalpha_in ? dalpha_in[(long)b * din_ld + p] : 0.f);
     }
 }
@@ -449,18 +449,27 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(int rows, int P, 
     const int tid = threadIdx.x;
     const int b = blockIdx.y, a0 = blockIdx.x * 64;
     float dot = 0.f;
-    for (int p = tid; p < P; p += 256) {
-        float da;
-        if (dt.tap_idx) {          // d alpha[p] = sum_k tap_w[p][k] * d alphaq[tap_idx[p][k]] (+ upstream d alphas)
-            da = dt.din ? dt.din[(long)b * dt.din_ld + p] : 0.f;
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                da = fmaf(dt.tap_w[p * 4 + k], dt.dalphaq[(long)b * dt.Q + dt.tap_idx[p * 4 + k]], da);
-        } else {
-            da = dalpha[(long)b * P + p];
+    if (dt.tap_idx) {              // d alpha[p] = sum_k tap_w[p][k] * d alphaq[tap_idx[p][k]] (+ upstream d alphas)
+        float* dq = part;          // [Q] staged first: the gather then needs no dependent global load
+        for (int q = tid; q < dt.Q; q += 256) dq[q] = dt.dalphaq[(long)b * dt.Q + q];
+        __syncthreads();
+        for (int p = tid; p < P; p += 256) {
+            const int4 ti = *reinterpret_cast<const int4*>(dt.tap_idx + p * 4);
+            const f32x4 tw = *reinterpret_cast<const f32x4*>(dt.tap_w + p * 4);
+            float da = dt.din ? dt.din[(long)b * dt.din_ld + p] : 0.f;
+            da = fmaf(tw[0], dq[ti.x], da);
+            da = fmaf(tw[1], dq[ti.y], da);
+            da = fmaf(tw[2], dq[ti.z], da);
+            da = fmaf(tw[3], dq[ti.w], da);
+            des[p] = da;
+            dot = fmaf(alpha[(long)b * P + p], da, dot);
         }
-        des[p] = da;
-        dot = fmaf(alpha[(long)b * P + p], da, dot);
+    } else {
+        for (int p = tid; p < P; p += 256) {
+            const float da = dalpha[(long)b * P + p];
+            des[p] = da;
+            dot = fmaf(alpha[(long)b * P + p], da, dot);
+        }
     }
     dot = block_reduce(dot, red, false);
     for (int p = tid; p < P; p += 256) {
@@ -679,16 +688,18 @@ int attn_dalpha(hipStream_t st, int rows, int P, int E, const float* enc, const 
                 const float* dalpha_in, long dalpha_in_ld, float* dalpha) {
     if (rows <= 0) return 0;
     SCN_ARG(enc && dawe && dalpha && P > 0 && E > 0, "attn_dalpha: bad argument");
-    dim3 grid(cdiv(P, PC), rows), block(256);
     const size_t lds = ((E + 3) & ~3) * sizeof(float);
     SCN_ARG(lds <= 64 * 1024, "attn_dalpha: encoder_dim too large for the LDS staging");
+    dim3 block(256);
     if (E % 4 == 0 && aligned16(enc)) {
-        if (g_attn_depth && E >= 1024)
-            hipLaunchKernelGGL((attn_dalpha_kernel<true, 4>), grid, block, lds, st, rows, P, E, enc, dawe, dalpha_in, dalpha_in_ld, dalpha);
+        if (g_attn_depth && E >= 2048 && P <= 128)       // few rows (the un-pooled map): more, shallower workgroups
+            hipLaunchKernelGGL((attn_dalpha_kernel<true, 8, 2>), dim3(cdiv(P, 8), rows), block, lds, st, rows, P, E, enc, dawe, dalpha_in, dalpha_in_ld, dalpha);
+        else if (g_attn_depth && E >= 1024)
+            hipLaunchKernelGGL((attn_dalpha_kernel<true, 4, 4>), dim3(cdiv(P, PC), rows), block, lds, st, rows, P, E, enc, dawe, dalpha_in, dalpha_in_ld, dalpha);
         else
-            hipLaunchKernelGGL((attn_dalpha_kernel<true, 2>), grid, block, lds, st, rows, P, E, enc, dawe, dalpha_in, dalpha_in_ld, dalpha);
+            hipLaunchKernelGGL((attn_dalpha_kernel<true, 2, 4>), dim3(cdiv(P, PC), rows), block, lds, st, rows, P, E, enc, dawe, dalpha_in, dalpha_in_ld, dalpha);
     } else {
-        hipLaunchKernelGGL((attn_dalpha_kernel<false, 2>), grid, block, lds, st, rows, P, E, enc, dawe, dalpha_in, dalpha_in_ld, dalpha);
+        hipLaunchKernelGGL((attn_dalpha_kernel<false, 2, 4>), dim3(cdiv(P, PC), rows), block, lds, st, rows, P, E, enc, dawe, dalpha_in, dalpha_in_ld, dalpha);
     }
     SCN_LAUNCH_CHECK();
     return 0;
@@ -720,7 +731,7 @@ int attn_softmax_bwd_pooled(hipStream_t st, int rows, int P, int A, const float*
             "attn_softmax_bwd_pooled: bad argument");
     dim3 grid(cdiv(A, 64), rows), block(256);
     const size_t lds = (16 * 64 + 16 + P) * sizeof(float);
-    SCN_ARG(lds <= 64 * 1024, "attn_softmax_bwd: num_pixels too large for the LDS staging");
+    SCN_ARG(lds <= 64 * 1024 && pool.Q <= 16 * 64, "attn_softmax_bwd: num_pixels too large for the LDS staging");
     const DalphaTaps dt{pool.tap_idx, pool.tap_w, dalphaq, pool.Q, dalpha_in, dalpha_in_ld};
     if (A % 4 == 0 && aligned16(att1))
         hipLaunchKernelGGL(attn_softmax_bwd_kernel<true>, grid, block, lds, st, rows, P, A, att1, att2, w, alpha, (const float*)nullptr, de, datt2, datt2_ld, dt);
