@@ -8,65 +8,50 @@ value (the reference's `is 'TRAIN'`, caption.py:58, relies on string interning),
 DataLoader workers works because every worker maps the file itself.
 """
 import json
-import os
 
 import torch
 from torch.utils.data import Dataset
 
-from scnattn import h5lite
+from datasets._mapped import SPLITS, MappedArrays, split_file, unit_float_image
 
 
 class CaptionDataset(Dataset):
-    r"""A PyTorch Dataset class to be used in a PyTorch DataLoader to create batches.
-
-    Arguments
-        data_folder (string): folder where data files are stored
-        data_name (string): base name of processed datasets
-        split (string): split, one of 'TRAIN', 'VAL', or 'TEST'
-        transform (callable): image transform pipeline
-        cpi (int): captions per image; falsy -> the file's `captions_per_image` attribute
-    """
+    """CaptionDataset(data_folder, data_name, split, transform=None, cpi=5): caption i with the image it
+    belongs to (image i // cpi); a falsy `cpi` takes the file's `captions_per_image` attribute."""
 
     def __init__(self, data_folder, data_name, split, transform=None, cpi=5):
-        self.split = split
-        assert self.split in {'TRAIN', 'VAL', 'TEST'}
-        self._path = os.path.join(data_folder, self.split + '_IMAGES_' + data_name + '.hdf5')
-        self.h = h5lite.File(self._path)
-        self.imgs = self.h['images']
-        self.cpi = cpi if cpi else int(self.h.attrs['captions_per_image'])
-        with open(os.path.join(data_folder, self.split + '_CAPTIONS_' + data_name + '.json'), 'r') as j:
-            self.captions = json.load(j)
-        with open(os.path.join(data_folder, self.split + '_CAPLENS_' + data_name + '.json'), 'r') as j:
+        assert split in SPLITS
+        self.split, self.transform = split, transform
+        self._arrays = MappedArrays(imgs=(split_file(data_folder, split, 'IMAGES', data_name, '.hdf5'), 'images'))
+        self.cpi = cpi if cpi else int(self._arrays.imgs_file.attrs['captions_per_image'])
+        with open(split_file(data_folder, split, 'CAPTIONS', data_name, '.json')) as j:
+            self.captions = json.load(j)          # whole files in memory, as the reference
+        with open(split_file(data_folder, split, 'CAPLENS', data_name, '.json')) as j:
             self.caplens = json.load(j)
-        self.transform = transform
         self.dataset_size = len(self.captions)
 
-    def __getstate__(self):            # DataLoader workers re-open the map instead of pickling it
-        st = dict(self.__dict__)
-        st['h'] = st['imgs'] = None
-        return st
+    @property
+    def imgs(self):
+        return self._arrays.imgs
 
-    def __setstate__(self, st):
-        self.__dict__.update(st)
-        self.h = h5lite.File(self._path)
-        self.imgs = self.h['images']
-
-    def __getitem__(self, i):
-        # the Nth caption corresponds to the (N // captions_per_image)th image
-        img = torch.FloatTensor(self.imgs[i // self.cpi] / 255.)
-        if self.transform is not None:
-            img = self.transform(img)
-        caption = torch.LongTensor(self.captions[i])
-        caplen = torch.LongTensor([self.caplens[i]])
-        if self.split == 'TRAIN':
-            return img, caption, caplen
-        # validation / test: also all `cpi` captions of the image, for BLEU-4
-        first = (i // self.cpi) * self.cpi
-        all_captions = torch.LongTensor(self.captions[first:first + self.cpi])
-        return img, caption, caplen, all_captions
+    @property
+    def h(self):
+        return self._arrays.imgs_file
 
     def __len__(self):
         return self.dataset_size
+
+    def __getitem__(self, i):
+        image_index = i // self.cpi
+        img = unit_float_image(self.imgs[image_index])
+        if self.transform is not None:
+            img = self.transform(img)
+        item = (img, torch.LongTensor(self.captions[i]), torch.LongTensor([self.caplens[i]]))
+        if self.split == 'TRAIN':
+            return item
+        # validation / test: all captions of the image too, for BLEU-4
+        first = image_index * self.cpi
+        return item + (torch.LongTensor(self.captions[first:first + self.cpi]),)
 
 
 class Normalize:
