@@ -138,3 +138,60 @@ def test_device_loader_full_size_rows_staged_equals_resident_and_ranks_partition
     it.close()                                    # generator finaliser stops the stager thread
     import threading
     assert not any(t.name == "scnattn-batch-stager" and t.is_alive() for t in threading.enumerate())
+
+
+def test_end_to_end_training_from_hdf5_files_learns(dev, tmp_path):
+    """Everything on the path at once, small: files in the reference's formats (written by h5lite) -> device batch
+    loader -> EncoderCaption (1-1-1-1 trunk, fine-tuned, channels-last, fused BN) -> AttentionSCN on the pooled
+    attention path -> fused loss -> fused clamp+Adam.  The model memorises 16 image/caption pairs: the loss must
+    fall by more than half in 60 steps, then validate() (eval forward, BLEU-4, top-5) runs on a VAL split."""
+    import json
+    from models.encoders.caption import EncoderCaption
+    from scnattn.resnet import resnet152_trunk
+    from trains.harness import TrainStep, validate
+    rng = np.random.RandomState(3)
+    base = "e2e_1_cap_per_img_0_min_word_freq"
+    V, L, N = 30, 9, 16
+    word_map = {"w%d" % i: i + 1 for i in range(V - 4)}
+    word_map.update({"<unk>": V - 3, "<start>": V - 2, "<end>": V - 1, "<pad>": 0})
+    for split in ("TRAIN", "VAL"):
+        imgs = rng.randint(0, 256, size=(N, 3, 64, 64)).astype(np.uint8)
+        h5lite.write_arrays(str(tmp_path / ("%s_IMAGES_%s.hdf5" % (split, base))), {"images": imgs},
+                            {"captions_per_image": 1})
+        caps, lens = [], []
+        for _ in range(N):
+            k = rng.randint(3, L - 1)
+            caps.append([V - 2] + rng.randint(1, V - 4, size=k).tolist() + [V - 1] + [0] * (L - 2 - k))
+            lens.append(k + 2)
+        json.dump(caps, open(str(tmp_path / ("%s_CAPTIONS_%s.json" % (split, base))), "w"))
+        json.dump(lens, open(str(tmp_path / ("%s_CAPLENS_%s.json" % (split, base))), "w"))
+    torch.manual_seed(0)
+    ts = TrainStep(kind="attention_scn", fine_tune_encoder=True, device=dev, encoder=False, seed=0, emb_dim=32,
+                   attention_dim=32, decoder_dim=48, factored_dim=32, semantic_dim=10, vocab_size=V, dropout=0.0,
+                   max_len=L - 2, decoder_lr=4e-3)
+    enc = EncoderCaption(channels_last=True)
+    enc.resnet = resnet152_trunk(depths=(1, 1, 1, 1))
+    enc = enc.to(dev).train()
+    enc.fine_tune(True)
+    from utils.optimizer import FusedClampAdam
+    enc_opt = FusedClampAdam([p for p in enc.parameters() if p.requires_grad], lr=1e-4, grad_clip=5.0)
+    loader = SD.DeviceBatchLoader(str(tmp_path), base, "TRAIN", 8, dev, cpi=1, shuffle=True, seed=0)
+    tags_all = torch.rand(N, 10, device=dev)
+    losses = []
+    for epoch in range(30):
+        loader.set_epoch(epoch)
+        order = SD.epoch_order(N, epoch, 0, True)
+        for b, (imgs, caps, caplens) in enumerate(loader):
+            tags = tags_all[torch.from_numpy(order[b * 8:(b + 1) * 8]).to(dev)]
+            enc_opt.zero_grad()
+            pre = enc(imgs, pooled=False)                       # (B, 2, 2, 2048): the trunk map of a 64x64 image
+            loss = ts.step(None, tags, caps, caplens, None, pre)
+            enc_opt.step()
+            losses.append(float(loss.detach()))
+    assert np.isfinite(losses).all()
+    first, last = np.mean(losses[:4]), np.mean(losses[-4:])
+    assert last < 0.5 * first, "loss did not fall: %.3f -> %.3f" % (first, last)
+    val = SD.DeviceBatchLoader(str(tmp_path), base, "VAL", 8, dev, cpi=1, shuffle=False)
+    bleu, vloss, top5 = validate(val, enc, lambda im: torch.rand(im.shape[0], 10, device=dev), ts.decoder,
+                                 torch.nn.CrossEntropyLoss().to(dev), word_map)
+    assert 0.0 <= bleu <= 1.0 and np.isfinite(vloss) and 0.0 <= top5 <= 100.0
