@@ -140,6 +140,14 @@ int scnattn_seq_bwd(void* stream, const scnattn_dims* d, const scnattn_params* w
 int scnattn_sgemm(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A,
                   long lda, const float* B, long ldb, float beta, float* C, long ldc, const float* bias,
                   const float* rowmask, int batch, long strideA, long strideB, long strideC);
+/* Same product with a caller-provided workspace of `ws_floats` floats for deterministic split-K partial sums:
+ * when the 128x128 tile grid alone cannot fill the chip (few rows: beam search, batch-4 configurations) the K
+ * range is divided over up to 16 workgroups per tile and reduced in a fixed order by a second launch.  ws may
+ * be NULL (then identical to scnattn_sgemm).  The workspace must not be shared by calls on different streams. */
+int scnattn_sgemm_ws(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A,
+                     long lda, const float* B, long ldb, float beta, float* C, long ldc, const float* bias,
+                     const float* rowmask, int batch, long strideA, long strideB, long strideC, float* ws,
+                     long ws_floats);
 /* Y[s][g][r][n] = sum_{k in slice s} X[r][g*xg+k] * W[g*wg + k*ldw + n]; ksplit<=0 picks one.
  * Returns the ksplit used through *ksplit_out. */
 int scnattn_skinny_gemm(void* stream, int rows, int N, int K, int groups, const float* X, long ldx, long xg,

@@ -104,6 +104,14 @@ int scnattn_sgemm(void* stream, int transA, int transB, int M, int N, int K, flo
                  batch < 1 ? 1 : batch, strideA, strideB, strideC);
 }
 
+int scnattn_sgemm_ws(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A,
+                     long lda, const float* B, long ldb, float beta, float* C, long ldc, const float* bias,
+                     const float* rowmask, int batch, long strideA, long strideB, long strideC, float* ws,
+                     long ws_floats) {
+    return sgemm_ws(ST(stream), transA != 0, transB != 0, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, rowmask,
+                    batch < 1 ? 1 : batch, strideA, strideB, strideC, ws, ws ? ws_floats : 0);
+}
+
 int scnattn_skinny_gemm(void* stream, int rows, int N, int K, int groups, const float* X, long ldx, long xg,
                         const float* W, long ldw, long wg, float* Y, long ldy, long yg, long yslab,
                         int ksplit, int* ksplit_out) {

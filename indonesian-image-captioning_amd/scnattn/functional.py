@@ -9,6 +9,7 @@ wrapper covers, by reference file:
   pool_permute     -> models/encoders/caption.py:41-43
 """
 import ctypes as C
+import threading
 
 import torch
 
@@ -34,9 +35,26 @@ def gemm(a, b, ta=False, tb=False, bias=None, out=None, beta=0.0, alpha=1.0, M=N
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=torch.float32)
     ldc = out.stride(0) if ldc is None else ldc
-    call("scnattn_sgemm", stream_of(a), int(ta), int(tb), M, N, K, alpha, ptr(a), lda, ptr(b), ldb, beta,
-         ptr(out), ldc, ptr(bias), ptr(rowmask), batch, sa, sb, sc)
+    ws = _gemm_workspace(a.device)
+    call("scnattn_sgemm_ws", stream_of(a), int(ta), int(tb), M, N, K, alpha, ptr(a), lda, ptr(b), ldb, beta,
+         ptr(out), ldc, ptr(bias), ptr(rowmask), batch, sa, sb, sc, ptr(ws), ws.numel())
     return out
+
+
+_gemm_ws = {}
+
+
+def _gemm_workspace(dev):
+    """32 MiB of split-K partial sums per (device, stream): the stand-alone modules' GEMMs have few rows (beam
+    search: k <= 5, PureAttention at batch 4), where the tile grid alone leaves most of the chip idle."""
+    # per host thread too: a GEMM is two launches (partials, then their reduction) and two threads enqueueing on
+    # one stream could interleave them
+    key = (dev, torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device()),
+           threading.get_ident())
+    ws = _gemm_ws.get(key)
+    if ws is None:
+        ws = _gemm_ws[key] = torch.empty(8 << 20, device=dev, dtype=torch.float32)
+    return ws
 
 
 def colsum(x, R=None, N=None, ld=None):
