@@ -46,3 +46,19 @@ def save_tagger_checkpoint(data_name, epoch, epochs_since_improvement, encoder, 
 
 def load_checkpoint(path, map_location=None):
     return torch.load(path, map_location=map_location, weights_only=False)
+
+
+def save_state_dicts(filename, encoder=None, decoder=None, tagger=None, **extra):
+    """The state-dict style the reference's inference / evaluation tooling reads but none of its scripts writes
+    (inference.py:93,118-129, eval_caption.py:65,77-85): `encoder_model_state_dict`, `decoder_model_state_dict`
+    for the caption model, `model_state_dict` for the tagger encoder.  Tensors only, so it loads with
+    `torch.load(..., weights_only=True)`."""
+    state = dict(extra)
+    if encoder is not None:
+        state['encoder_model_state_dict'] = encoder.state_dict()
+    if decoder is not None:
+        state['decoder_model_state_dict'] = decoder.state_dict()
+    if tagger is not None:
+        state['model_state_dict'] = tagger.state_dict()
+    torch.save(state, filename)
+    return filename

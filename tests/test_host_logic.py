@@ -313,3 +313,23 @@ def test_pool_taps_encode_adaptive_avg_pool(hin, hout):
     assert torch.allclose(pt.col_w.double(), m.sum(dim=0) / pt.P)
     with pytest.raises(ValueError):
         SF.PoolTaps(14, 14, 4, 4, "cpu")
+
+
+def test_state_dict_checkpoint_feeds_the_reference_tooling_keys(tmp_path):
+    """inference.py:118-129 / eval_caption.py:77-85 read `encoder_model_state_dict` / `decoder_model_state_dict`
+    (and `model_state_dict` for the tagger); such a file loads with weights_only=True and rebuilds the decoder
+    through utils.loader.load_decoder."""
+    from models.decoders.pure_scn import PureSCN
+    from utils.checkpoint import save_state_dicts
+    from utils.loader import load_decoder
+    torch.manual_seed(1)
+    dec = PureSCN(12, 16, 20, 1000, 30)
+    enc = torch.nn.Linear(3, 3)
+    path = save_state_dicts(str(tmp_path / "caption.pth"), encoder=enc, decoder=dec, epoch=4)
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    assert set(ck) == {"encoder_model_state_dict", "decoder_model_state_dict", "epoch"} and ck["epoch"] == 4
+    again = load_decoder("pure_scn", ck["decoder_model_state_dict"], 30, embed_dim=12, decoder_dim=16, factored_dim=20)
+    for (k, a), (_, b) in zip(dec.state_dict().items(), again.state_dict().items()):
+        assert torch.equal(a, b.cpu()), k
+    t = save_state_dicts(str(tmp_path / "tagger.pth"), tagger=enc)
+    assert set(torch.load(t, weights_only=True)) == {"model_state_dict"}
