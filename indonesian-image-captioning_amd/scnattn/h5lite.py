@@ -45,7 +45,7 @@ class _Reader:
         self.base = 0
 
     def u(self, off, n):
-        if off < 0 or off + n > len(self.b):
+        if off < 0 or off > len(self.b) or off + n > len(self.b):
             raise H5Error("truncated HDF5 file (read of %d bytes at offset %d past end %d)" % (n, off, len(self.b)))
         return int.from_bytes(self.b[off:off + n], "little")
 
@@ -61,10 +61,22 @@ class _Reader:
         return bytes(self.b[off:off + n])
 
     def cstr(self, off, limit=4096):
-        end = self.b.find(b"\0", off, off + limit)
+        if off < 0 or off >= len(self.b):
+            raise H5Error("string offset outside the file (corrupt HDF5 structure)")
+        end = self.b.find(b"\0", off, min(off + limit, len(self.b)))
         if end < 0:
             raise H5Error("unterminated string in HDF5 heap")
-        return bytes(self.b[off:end]).decode("utf-8")
+        try:
+            return bytes(self.b[off:end]).decode("utf-8")
+        except UnicodeDecodeError:
+            raise H5Error("name is not valid UTF-8 (corrupt HDF5 structure)")
+
+    def budget(self, what="structure"):
+        """Every object-header block / B-tree node visited draws on one budget, so that cyclic or absurdly
+        wide (corrupt) structures end in an error instead of a hang."""
+        self.visits = getattr(self, "visits", 0) + 1
+        if self.visits > 200000:
+            raise H5Error("HDF5 %s too large or cyclic (corrupt file?)" % what)
 
 
 def _pad8(n):
@@ -108,7 +120,14 @@ def _parse_dataspace(r, pos):
         p = pos + 4
     else:
         raise H5Error("unsupported dataspace message version %d" % ver)
+    if rank > 32:
+        raise H5Error("dataspace of rank %d (corrupt HDF5 structure)" % rank)
     shape = tuple(r.len_(p + i * r.L) for i in range(rank))
+    total = 1
+    for dim in shape:
+        total *= dim
+        if total > (1 << 48):
+            raise H5Error("dataspace with an implausible element count (corrupt HDF5 structure)")
     size = (p - pos) + rank * r.L * (2 if flags & 1 else 1)
     return shape, size
 
@@ -135,6 +154,7 @@ class _Object:
         blocks = [(addr + 16, hsize)]   # 12 bytes of prefix + 4 of alignment padding
         seen = 0
         while blocks and seen < nmsg:
+            r.budget("object header")
             pos, left = blocks.pop(0)
             end = pos + left
             while pos + 8 <= end and seen < nmsg:
@@ -163,6 +183,7 @@ class _Object:
         track = bool(flags & 0x04)
         blocks = [(pos, chunk0)]
         while blocks:
+            r.budget("object header")
             pos, left = blocks.pop(0)
             end = pos + left
             while pos + 4 <= end:
@@ -170,9 +191,10 @@ class _Object:
                 data = pos + 4 + (2 if track else 0)
                 if data + msize > end:
                     break
+                r.budget("object header")
                 if mtype == 0x10:
                     caddr, clen = r.base + r.off(data), r.len_(data + r.O)
-                    if r.bytes(caddr, 4) != b"OCHK":
+                    if clen < 8 or r.bytes(caddr, 4) != b"OCHK":
                         raise H5Error("bad object header continuation signature")
                     blocks.append((caddr + 4, clen - 8))   # minus signature and checksum
                 elif mtype != 0:
@@ -268,6 +290,7 @@ class _Object:
 
     def _walk_group_btree(self, addr, hdata, out, depth):
         r = self.r
+        r.budget("group B-tree")
         if depth > 16:
             raise H5Error("group B-tree too deep")
         if r.bytes(addr, 4) != b"TREE" or r.u(addr + 4, 1) != 0:
@@ -288,10 +311,30 @@ class _Object:
                 out[r.cstr(hdata + r.off(e))] = r.base + r.off(e + r.O)
 
 
+_PARSE_ERRORS = (ValueError, OverflowError, IndexError, struct.error, MemoryError, RecursionError, TypeError)
+
+
+def _guard(fn):
+    """Anything a corrupt byte can provoke inside the parser surfaces as H5Error."""
+    def wrapped(*a, **k):
+        try:
+            return fn(*a, **k)
+        except H5Error:
+            raise
+        except KeyError:
+            raise
+        except _PARSE_ERRORS as e:
+            raise H5Error("corrupt or unsupported HDF5 structure (%s: %s)" % (type(e).__name__, e))
+    wrapped.__name__ = fn.__name__
+    wrapped.__doc__ = fn.__doc__
+    return wrapped
+
+
 class Dataset:
     """Read-only view of one dataset.  `ds[i]`, `ds[a:b]`, `ds[[3, 1, 2]]` return numpy arrays like h5py;
     `ds.array` is the zero-copy memory map (contiguous layout) used by the batch loader."""
 
+    @_guard
     def __init__(self, f, name, obj):
         r = f._r
         self.file, self.name, self._obj = f, name, obj
@@ -344,15 +387,20 @@ class Dataset:
             raise H5Error("unsupported data layout class %d" % cls)
 
     # ---- chunked storage, unfiltered -------------------------------------------------------------------
+    @_guard
     def _load_chunked(self):
         r = self.file._r
         btree, cdims = self._chunks
+        nbytes = int(np.prod(self.shape, dtype=np.float64)) * self.dtype.itemsize
+        if nbytes > 64 * len(r.b) + (1 << 20) or any(c <= 0 for c in cdims):
+            raise H5Error("chunked dataset '%s' claims %d bytes in a %d-byte file (corrupt?)" % (self.name, nbytes, len(r.b)))
         out = np.zeros(self.shape, self.dtype)
         if btree is None:
             return out
         rank = len(self.shape)
 
         def walk(addr, depth):
+            r.budget("chunk B-tree")
             if depth > 32 or r.bytes(addr, 4) != b"TREE" or r.u(addr + 4, 1) != 1:
                 raise H5Error("bad chunk B-tree node at %d" % addr)
             level, used = r.u(addr + 5, 1), r.u(addr + 6, 2)
@@ -415,6 +463,7 @@ class File:
             self.close()
             raise
 
+    @_guard
     def _open(self):
         mm = self._mm
         start = 0
@@ -452,6 +501,7 @@ class File:
     def __contains__(self, name):
         return name in self._links
 
+    @_guard
     def __getitem__(self, name):
         name = name.lstrip("/")
         if name not in self._links:

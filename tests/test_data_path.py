@@ -182,3 +182,40 @@ def test_device_loader_has_no_cpu_fallback():
         SD.DeviceBatchLoader(G, BASE, "TRAIN", 2, "cpu", cpi=2)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         SD.gather_normalize(torch.zeros(1, 3, 4, 4, dtype=torch.uint8), None, torch.zeros(3, 256))
+
+
+def test_h5lite_corrupt_files_fail_cleanly(tmp_path):
+    """Bounded fuzz: random byte flips in the metadata region and random truncation of valid files must end in
+    H5Error / KeyError (or succeed), never in another exception, a hang or a giant allocation."""
+    import random
+    import signal
+    rng = random.Random(4)
+
+    def on_alarm(*_):
+        raise AssertionError("h5lite hung on a corrupt file")
+    old = signal.signal(signal.SIGALRM, on_alarm)
+    try:
+        for name in ("small_contiguous.hdf5", "small_latest.hdf5", "small_chunked.hdf5", "small_many_links.hdf5"):
+            data = open(os.path.join(G, name), "rb").read()
+            for trial in range(120):
+                d = bytearray(data)
+                for _ in range(rng.randint(1, 4)):
+                    d[rng.randrange(min(len(d), 4096))] = rng.randrange(256)
+                if rng.random() < 0.2:
+                    d = d[:rng.randrange(32, len(d))]
+                p = tmp_path / "fuzz.hdf5"
+                p.write_bytes(bytes(d))
+                signal.alarm(10)
+                try:
+                    with h5lite.File(str(p)) as f:
+                        for k in f.keys()[:50]:
+                            try:
+                                f[k][:]
+                            except (h5lite.H5Error, KeyError):
+                                pass
+                except (h5lite.H5Error, KeyError):
+                    pass
+                finally:
+                    signal.alarm(0)
+    finally:
+        signal.signal(signal.SIGALRM, old)
