@@ -127,3 +127,23 @@ x = R(6272, 512)
 timeit("colsum 6272x512", lambda: SF.colsum(x), bytes_=4 * 6272 * 512, iters=10)
 x2 = R(1632, 2048)
 timeit("colsum 1632x2048", lambda: SF.colsum(x2), bytes_=4 * 1632 * 2048, iters=10)
+
+# library baseline for the same products (torch.mm -> hipBLASLt / rocBLAS): what a "plain library GEMM" would give
+if not flt or "lib" in flt:
+    def lib(name, M, N, K, ta=False, tb=False):
+        a = R(K, M) if ta else R(M, K)
+        b = R(N, K) if tb else R(K, N)
+        out = torch.empty(M, N, device=dev)
+        timeit("lib   %s %dx%dx%d %s%s" % (name, M, N, K, "T" if ta else "N", "T" if tb else "N"),
+               lambda: torch.mm(a.t() if ta else a, b.t() if tb else b, out=out), flops=2 * M * N * K, iters=10)
+    lib("att1", 6272, 512, 2048, tb=True)
+    lib("y", 2048, 512, 2048, tb=True)
+    lib("fc", 1632, 10000, 512, tb=True)
+    lib("dHd", 1632, 512, 10000)
+    lib("dWfc", 10000, 512, 1632, ta=True)
+    lib("dWe", 512, 2048, 6272, ta=True)
+    lib("dWa", 2048, 2048, 1632, ta=True)
+    lib("ex", 1632, 2048, 512)
+    lib("dWaM", 512, 2048, 1632, ta=True)
+    lib("demb", 1632, 512, 2048, tb=True)
+    lib("sq4096", 4096, 4096, 4096)
