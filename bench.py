@@ -246,6 +246,8 @@ def main():
     if args.data != "synthetic":
         batches = hdf5_batches(args, cfg, dev, rank, world)
 
+    last_loss = [None]
+
     def run(n):
         nonlocal imgs, caps, caplens
         for _ in range(n):
@@ -256,7 +258,7 @@ def main():
                     ts.decoder(enc_in, tags, caps, caplens, prepool=pre_in) if pre_in is not None else \
                         ts.decoder(enc_in, tags, caps, caplens)
             else:
-                ts.step(imgs, tags, caps, caplens, enc_in, pre_in)
+                last_loss[0] = ts.step(imgs, tags, caps, caplens, enc_in, pre_in)
 
     run(args.warmup)
     SF.set_option("profile", 1)
@@ -291,6 +293,11 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    if last_loss[0] is not None:     # outside the timed region: the model must still be training on finite numbers
+        final_loss = float(last_loss[0].detach())
+        assert final_loss == final_loss and abs(final_loss) < 1e6, "loss diverged: %r" % final_loss
+    else:
+        final_loss = None
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
         value = world * args.batch * args.steps / elapsed
@@ -300,7 +307,7 @@ def main():
             else "images/sec (train step, %s, bs%d/GPU)" % (args.workload, args.batch),
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None,
+            "vs_baseline": None, "loss_after_timed_steps": None if final_loss is None else round(final_loss, 4),
             "dtype": "f32" if args.encoder_dtype == "f32" else "bf16 encoder convs (fp32 accumulate/master) + f32 decoder",
             "data": "synthetic" if args.data == "synthetic" else
             "synthetic %d-image HDF5 split read through scnattn.data.DeviceBatchLoader (%s) inside the timed region"
