@@ -204,10 +204,11 @@ int check_bt(const scnattn_dims* d, const int32_t* bt) {
 int check_pool(const scnattn_dims* d, const scnattn_pool* p, PoolDesc& out) {
     out = PoolDesc{0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (!p) return 0;
-    SCN_ARG(d->has_att, "scnattn_pool: only the attention decoders read encoder_out inside the loop");
+    // (without attention only the initial state reads encoder_out: its pixel mean becomes a weighted mean of x)
     SCN_ARG(p->Q > 0 && p->Q <= d->P && p->qtap_max > 0 && p->qtap_max <= 64, "scnattn_pool: bad Q / qtap_max");
     SCN_ARG(p->tap_idx && p->tap_w && p->qtap_idx && p->qtap_w && p->col_w, "scnattn_pool: null table");
-    SCN_ARG(d->A % 4 == 0 && d->E % 4 == 0, "scnattn_pool: attention_dim and encoder_dim must be multiples of 4");
+    SCN_ARG((!d->has_att || d->A % 4 == 0) && d->E % 4 == 0,
+            "scnattn_pool: attention_dim and encoder_dim must be multiples of 4");
     out = PoolDesc{p->Q, p->qtap_max, p->tap_idx, p->tap_w, p->qtap_idx, p->qtap_w, p->col_w};
     return 0;
 }
@@ -634,10 +635,14 @@ int seq_bwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
     // ---- d loss / d encoder_out (only when the encoder is fine-tuned) -------------------------------
     if (denc && Q > 0) {
         // d x = d y . We  +  sum_t alphaq_t (x) dawe_t  +  col_w (x) d mean      (all on the Q source pixels)
-        SCN_TRY(sgemm_ws(st, false, false, B * Q, E, A, 1.f, k.dy, A, w->attention_encoder_att_weight, E, 0.f, denc, E,
-                      nullptr, nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
-        SCN_TRY(sgemm_ws(st, true, false, Q, E, T, 1.f, s.alphaq_tm, (long)B * Q, k.dawe_all, (long)B * E, 1.f, denc, E,
-                      nullptr, nullptr, B, Q, E, (long)Q * E, k.gws, GEMM_WS_FLOATS));
+        if (d.has_att) {
+            SCN_TRY(sgemm_ws(st, false, false, B * Q, E, A, 1.f, k.dy, A, w->attention_encoder_att_weight, E, 0.f, denc,
+                          E, nullptr, nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
+            SCN_TRY(sgemm_ws(st, true, false, Q, E, T, 1.f, s.alphaq_tm, (long)B * Q, k.dawe_all, (long)B * E, 1.f, denc,
+                          E, nullptr, nullptr, B, Q, E, (long)Q * E, k.gws, GEMM_WS_FLOATS));
+        } else {
+            SCN_HIP(hipMemsetAsync(denc, 0, sizeof(float) * B * Q * E, st));
+        }
         SCN_TRY(sgemm_ws(st, false, false, B, E, D, 1.f, k.dh0, D, w->init_h_weight, E, 0.f, k.dmean, E, nullptr, nullptr,
                       1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
         SCN_TRY(sgemm_ws(st, false, false, B, E, D, 1.f, k.dc, D, w->init_c_weight, E, 1.f, k.dmean, E, nullptr, nullptr,

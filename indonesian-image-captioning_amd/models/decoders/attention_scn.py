@@ -68,7 +68,7 @@ class AttentionSCN(nn.Module):
         SURVEY 8d); `encoder_out` may then be None."""
         pre = prepool if prepool is not None else _common.attached_prepool(encoder_out)
         pool = None
-        if pre is not None and pre.is_cuda and pre.dim() == 4:
+        if pre is not None and pre.is_cuda and pre.dim() == 4 and pre.shape[-1] % 4 == 0 and self.attention_dim % 4 == 0:
             out_hw = tuple(encoder_out.shape[1:3]) if encoder_out is not None else (pool_size, pool_size)
             try:
                 pool = SF.pool_taps(pre.shape[1], pre.shape[2], out_hw[0], out_hw[1], pre.device)

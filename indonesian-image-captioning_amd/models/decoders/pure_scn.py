@@ -43,16 +43,31 @@ class PureSCN(nn.Module):
         return (SF.linear(mean_encoder_out, self.init_h.weight, self.init_h.bias),
                 SF.linear(mean_encoder_out, self.init_c.weight, self.init_c.bias))
 
-    def forward(self, encoder_out, semantic_input, encoded_captions, caption_lengths, sort_ind=None):
+    def forward(self, encoder_out, semantic_input, encoded_captions, caption_lengths, sort_ind=None, prepool=None,
+                pool_size=14):
+        """Reference signature (pure_scn.py:87) plus the optional trunk map (see AttentionSCN.forward): only the
+        initial state reads the encoder output here, and the pixel mean of the pooled map is a weighted mean of
+        the un-pooled one."""
+        pre = prepool if prepool is not None else _common.attached_prepool(encoder_out)
+        pool = None
+        if pre is not None and pre.is_cuda and pre.dim() == 4 and pre.shape[-1] % 4 == 0:
+            out_hw = tuple(encoder_out.shape[1:3]) if encoder_out is not None else (pool_size, pool_size)
+            try:
+                pool = SF.pool_taps(pre.shape[1], pre.shape[2], out_hw[0], out_hw[1], pre.device)
+            except ValueError:
+                pool = None
+        if pool is None and encoder_out is None:
+            raise RuntimeError("PureSCN.forward: encoder_out is None and no usable prepool map was given")
         enc, caps, decode_lengths, dl_dev, sort_ind = _common.sort_by_length(
-            encoder_out, encoded_captions, caption_lengths, sort_ind)
-        B, P, E = enc.shape
+            pre if pool is not None else encoder_out, encoded_captions, caption_lengths, sort_ind)
+        B, E = enc.shape[0], enc.shape[2]
+        P = pool.P if pool is not None else enc.shape[1]
         T = max(decode_lengths)
         dims = (B, P, E, 0, self.decoder_dim, self.factored_dim, self.embed_dim, self.semantic_dim,
                 self.vocab_size, T, caps.size(1), 0)
         mask = _common.make_drop_mask(self, B, T, self.decoder_dim, enc.device)
         predictions, _ = SF.decoder_sequence(dims, _common.active_rows(decode_lengths), enc, semantic_input, caps,
-                                             dl_dev, mask, _collect_weights(self))
+                                             dl_dev, mask, _collect_weights(self), pool)
         return predictions, caps, decode_lengths, sort_ind
 
     def sample(self, beam_size, word_map, encoder_out, tag_out):

@@ -1079,3 +1079,28 @@ def test_encoder_attaches_prepool_and_decoder_uses_it(dev):
         y.mul_(1.0)                                   # in-place touch: version counter moves, tag is void
         assert _common.attached_prepool(y) is None
         assert _common.attached_prepool(y * 1.0) is None
+
+
+def test_pure_scn_pooled_path_equals_dense_path(dev):
+    """PureSCN reads the encoder output only through its pixel mean (pure_scn.py:76-85): with the trunk map that
+    mean is a weighted mean of the 64 source pixels; predictions, gradients and d x must match the dense path."""
+    from models.decoders.pure_scn import PureSCN
+    torch.manual_seed(9)
+    B, V, L, E = 5, 40, 8, 64
+    m = PureSCN(24, 32, 40, 12, V, encoder_dim=E, dropout=0.0).to(dev).train()
+    x = torch.rand(B, 8, 8, E, device=dev)
+    tags = torch.rand(B, 12, device=dev)
+    caps = torch.randint(1, V - 3, (B, L), device=dev)
+    caplens = torch.tensor([[8], [8], [6], [4], [3]], device=dev)
+    res = []
+    for pooled in (False, True):
+        m.zero_grad(set_to_none=True)
+        xx = x.clone().requires_grad_(True)
+        enc = torch.nn.functional.adaptive_avg_pool2d(xx.permute(0, 3, 1, 2), 14).permute(0, 2, 3, 1)
+        out = m(None, tags, caps, caplens, prepool=xx) if pooled else m(enc, tags, caps, caplens)
+        out[0].square().sum().backward()
+        res.append((out[0].detach(), xx.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    _ok(res[1][0], res[0][0], 1e-5, "predictions")
+    assert rel_l2(res[1][1], res[0][1]) <= 2e-5
+    for k in res[0][2]:
+        assert rel_l2(res[1][2][k], res[0][2][k]) <= 5e-5, k
