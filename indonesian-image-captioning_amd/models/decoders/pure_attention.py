@@ -1,13 +1,24 @@
 """PureAttention on MI355X: drop-in for the reference's models/decoders/pure_attention.py
-(Show-Attend-Tell: soft attention + a plain LSTMCell, no tags).  BASELINE config 1 uses it as
-plumbing only, so the loop stays step-by-step: the attention (models/attention.py) and every Linear
-run in libscnattn; the LSTMCell is torch's own (its state_dict keys must stay torch's)."""
+(Show-Attend-Tell: soft attention + a plain `nn.LSTMCell`, no tags).
+
+The teacher-forced forward runs through the same whole-sequence HIP drivers as AttentionSCN: an LSTM cell is
+the SCN cell with the tag factors switched off.  With  s.Wb = s.Hb = 1  (one constant "tag", weights of ones)
+and  Wc_g = Hc_g = I  (factored_dim = decoder_dim), the SCN pre-activation
+    r_g = ((u.Wa_g) * (s.Wb_g)) . Wc_g^T + b_ih_g + ((h.Ha_g) * (s.Hb_g)) . Hc_g^T + b_hh_g        (scn_cell.py:73-144)
+is  u.Wa_g + h.Ha_g + b_ih_g + b_hh_g, the LSTMCell's (pure_attention.py:60, 140-141), once the LSTMCell's
+[4H, I] / [4H, H] matrices are transposed and its gate blocks (torch order i, f, g, o) put in the SCN order
+(i, f, o, c).  The identity products are exact in fp32, autograd carries the gradients back through that
+re-layout to `decode_step.weight_ih` etc., and the state_dict keys stay torch's.  `forward_stepwise` is the
+literal loop (attention + Linears in libscnattn, torch's LSTMCell), kept as an in-box cross-check; beam search
+(`sample`) uses the cell step by step as the reference does."""
 import torch
 from torch import nn
 
 from models.attention import Attention
 from models.decoders import _common
+from models.decoders.attention_scn import _KEY_OF_FIELD
 from scnattn import functional as SF
+from scnattn._lib import PARAM_FIELDS
 
 
 class PureAttention(nn.Module):
@@ -46,7 +57,40 @@ class PureAttention(nn.Module):
         return (SF.linear(mean_encoder_out, self.init_h.weight, self.init_h.bias),
                 SF.linear(mean_encoder_out, self.init_c.weight, self.init_c.bias))
 
+    def _scn_view_of_lstm(self):
+        """The LSTMCell as SCN-cell weights in scnattn_params order (see the module docstring)."""
+        H = self.decoder_dim
+        cell = self.decode_step
+        dev = cell.weight_ih.device
+        idx = torch.cat([torch.arange(0, 2 * H), torch.arange(3 * H, 4 * H), torch.arange(2 * H, 3 * H)]).to(dev)
+        ones = torch.ones(1, 4 * H, device=dev)
+        eye4 = torch.eye(H, device=dev).repeat(1, 4)
+        scn = {
+            "decode_step_weight_ia": cell.weight_ih.index_select(0, idx).t().contiguous(),
+            "decode_step_weight_ib": ones, "decode_step_weight_ic": eye4,
+            "decode_step_weight_ha": cell.weight_hh.index_select(0, idx).t().contiguous(),
+            "decode_step_weight_hb": ones, "decode_step_weight_hc": eye4,
+            "decode_step_bias_ih": cell.bias_ih.index_select(0, idx),
+            "decode_step_bias_hh": cell.bias_hh.index_select(0, idx),
+        }
+        named = dict(self.named_parameters())
+        return [scn[f] if f in scn else named.get(_KEY_OF_FIELD[f]) for f in PARAM_FIELDS]
+
     def forward(self, encoder_out, encoded_captions, caption_lengths, sort_ind=None):
+        enc, caps, decode_lengths, dl_dev, sort_ind = _common.sort_by_length(
+            encoder_out, encoded_captions, caption_lengths, sort_ind)
+        B, P, E = enc.shape
+        T = max(decode_lengths)
+        H = self.decoder_dim
+        dims = (B, P, E, self.attention_dim, H, H, self.embed_dim, 1, self.vocab_size, T, caps.size(1), 1)
+        mask = _common.make_drop_mask(self, B, T, H, enc.device)
+        ones = torch.ones(B, 1, device=enc.device)                 # the single constant "tag"
+        predictions, alphas = SF.decoder_sequence(dims, _common.active_rows(decode_lengths), enc, ones, caps, dl_dev,
+                                                  mask, self._scn_view_of_lstm())
+        return predictions, caps, decode_lengths, alphas, sort_ind
+
+    def forward_stepwise(self, encoder_out, encoded_captions, caption_lengths, sort_ind=None):
+        """The reference's loop as written (pure_attention.py:120-149), one timestep at a time."""
         enc, caps, decode_lengths, _, sort_ind = _common.sort_by_length(
             encoder_out, encoded_captions, caption_lengths, sort_ind)
         B, P, _ = enc.shape

@@ -1104,3 +1104,31 @@ def test_pure_scn_pooled_path_equals_dense_path(dev):
     assert rel_l2(res[1][1], res[0][1]) <= 2e-5
     for k in res[0][2]:
         assert rel_l2(res[1][2][k], res[0][2][k]) <= 5e-5, k
+
+
+def test_pure_attention_sequence_driver_equals_stepwise_loop(dev):
+    """PureAttention.forward (LSTMCell expressed as an SCN cell with unit tag factors and identity third factors,
+    one C call each way) against its literal step-by-step loop with torch's own LSTMCell: outputs and every
+    gradient, including decode_step.weight_ih / weight_hh / biases through the gate re-ordering, ragged lengths."""
+    from models.decoders.pure_attention import PureAttention
+    torch.manual_seed(17)
+    B, V, L = 6, 45, 9
+    m = PureAttention(24, 20, 32, V, encoder_dim=64, dropout=0.0).to(dev).train()
+    enc = torch.rand(B, 4, 4, 64, device=dev)
+    caps = torch.randint(1, V - 3, (B, L), device=dev)
+    caplens = torch.tensor([[9], [9], [7], [5], [4], [2]], device=dev)
+    res = []
+    for fn in (m.forward_stepwise, m.forward):
+        m.zero_grad(set_to_none=True)
+        e = enc.clone().requires_grad_(True)
+        p, _, dl, a, _ = fn(e, caps, caplens)
+        (p.square().sum() + (a * a).sum()).backward()
+        res.append((p.detach(), a.detach(), e.grad.clone(), {k: q.grad.clone() for k, q in m.named_parameters()}))
+    _ok(res[1][0], res[0][0], 1e-5, "predictions")
+    _ok(res[1][1], res[0][1], 1e-5, "alphas")
+    assert rel_l2(res[1][2], res[0][2]) <= 1e-4, rel_l2(res[1][2], res[0][2])
+    for k in res[0][3]:
+        if k.endswith("full_att.bias"):
+            assert (res[1][3][k] - res[0][3][k]).abs().max().item() <= 1e-4
+            continue
+        assert rel_l2(res[1][3][k], res[0][3][k]) <= 1e-4, "%s: %.3e" % (k, rel_l2(res[1][3][k], res[0][3][k]))
