@@ -47,6 +47,24 @@ def attached_prepool(encoder_out):
     return pre
 
 
+def resolve_prepool(encoder_out, prepool, pool_size, attention_dim=None, who="forward"):
+    """-> (tensor to sort/permute, PoolTaps or None).  The trunk map (B, h, w, E) is used instead of the pooled
+    encoder_out when it was given (or attached by EncoderCaption), lives on the GPU, has vector-friendly widths
+    and the pooling is an up-sampling one (windows of at most 2x2); otherwise the dense path is taken."""
+    pre = prepool if prepool is not None else attached_prepool(encoder_out)
+    pool = None
+    if pre is not None and pre.is_cuda and pre.dim() == 4 and pre.shape[-1] % 4 == 0 \
+            and (attention_dim is None or attention_dim % 4 == 0):
+        out_hw = tuple(encoder_out.shape[1:3]) if encoder_out is not None else (pool_size, pool_size)
+        try:
+            pool = SF.pool_taps(pre.shape[1], pre.shape[2], out_hw[0], out_hw[1], pre.device)
+        except ValueError:
+            pool = None
+    if pool is None and encoder_out is None:
+        raise RuntimeError("%s: encoder_out is None and no usable prepool map was given" % who)
+    return (pre if pool is not None else encoder_out), pool
+
+
 def active_rows(decode_lengths):
     return [sum(l > t for l in decode_lengths) for t in range(max(decode_lengths))]
 

@@ -66,18 +66,9 @@ class AttentionSCN(nn.Module):
         given it -- explicitly, or attached by this build's EncoderCaption to the tensor it returned -- the
         attention runs on the h*w source pixels and the pooled map is not read (same numbers by linearity,
         SURVEY 8d); `encoder_out` may then be None."""
-        pre = prepool if prepool is not None else _common.attached_prepool(encoder_out)
-        pool = None
-        if pre is not None and pre.is_cuda and pre.dim() == 4 and pre.shape[-1] % 4 == 0 and self.attention_dim % 4 == 0:
-            out_hw = tuple(encoder_out.shape[1:3]) if encoder_out is not None else (pool_size, pool_size)
-            try:
-                pool = SF.pool_taps(pre.shape[1], pre.shape[2], out_hw[0], out_hw[1], pre.device)
-            except ValueError:
-                pool = None                      # not an up-sampling pool: dense path
-        if pool is None and encoder_out is None:
-            raise RuntimeError("AttentionSCN.forward: encoder_out is None and no usable prepool map was given")
+        src, pool = _common.resolve_prepool(encoder_out, prepool, pool_size, self.attention_dim, "AttentionSCN.forward")
         enc, caps, decode_lengths, dl_dev, sort_ind = _common.sort_by_length(
-            pre if pool is not None else encoder_out, encoded_captions, caption_lengths, sort_ind)
+            src, encoded_captions, caption_lengths, sort_ind)
         B, E = enc.shape[0], enc.shape[2]
         P = pool.P if pool is not None else enc.shape[1]
         T = max(decode_lengths)

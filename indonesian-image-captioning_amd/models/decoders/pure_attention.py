@@ -76,17 +76,19 @@ class PureAttention(nn.Module):
         named = dict(self.named_parameters())
         return [scn[f] if f in scn else named.get(_KEY_OF_FIELD[f]) for f in PARAM_FIELDS]
 
-    def forward(self, encoder_out, encoded_captions, caption_lengths, sort_ind=None):
+    def forward(self, encoder_out, encoded_captions, caption_lengths, sort_ind=None, prepool=None, pool_size=14):
+        src, pool = _common.resolve_prepool(encoder_out, prepool, pool_size, self.attention_dim, "PureAttention.forward")
         enc, caps, decode_lengths, dl_dev, sort_ind = _common.sort_by_length(
-            encoder_out, encoded_captions, caption_lengths, sort_ind)
-        B, P, E = enc.shape
+            src, encoded_captions, caption_lengths, sort_ind)
+        B, E = enc.shape[0], enc.shape[2]
+        P = pool.P if pool is not None else enc.shape[1]
         T = max(decode_lengths)
         H = self.decoder_dim
         dims = (B, P, E, self.attention_dim, H, H, self.embed_dim, 1, self.vocab_size, T, caps.size(1), 1)
         mask = _common.make_drop_mask(self, B, T, H, enc.device)
         ones = torch.ones(B, 1, device=enc.device)                 # the single constant "tag"
         predictions, alphas = SF.decoder_sequence(dims, _common.active_rows(decode_lengths), enc, ones, caps, dl_dev,
-                                                  mask, self._scn_view_of_lstm())
+                                                  mask, self._scn_view_of_lstm(), pool)
         return predictions, caps, decode_lengths, alphas, sort_ind
 
     def forward_stepwise(self, encoder_out, encoded_captions, caption_lengths, sort_ind=None):

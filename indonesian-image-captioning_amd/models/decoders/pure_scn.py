@@ -48,18 +48,9 @@ class PureSCN(nn.Module):
         """Reference signature (pure_scn.py:87) plus the optional trunk map (see AttentionSCN.forward): only the
         initial state reads the encoder output here, and the pixel mean of the pooled map is a weighted mean of
         the un-pooled one."""
-        pre = prepool if prepool is not None else _common.attached_prepool(encoder_out)
-        pool = None
-        if pre is not None and pre.is_cuda and pre.dim() == 4 and pre.shape[-1] % 4 == 0:
-            out_hw = tuple(encoder_out.shape[1:3]) if encoder_out is not None else (pool_size, pool_size)
-            try:
-                pool = SF.pool_taps(pre.shape[1], pre.shape[2], out_hw[0], out_hw[1], pre.device)
-            except ValueError:
-                pool = None
-        if pool is None and encoder_out is None:
-            raise RuntimeError("PureSCN.forward: encoder_out is None and no usable prepool map was given")
+        src, pool = _common.resolve_prepool(encoder_out, prepool, pool_size, None, "PureSCN.forward")
         enc, caps, decode_lengths, dl_dev, sort_ind = _common.sort_by_length(
-            pre if pool is not None else encoder_out, encoded_captions, caption_lengths, sort_ind)
+            src, encoded_captions, caption_lengths, sort_ind)
         B, E = enc.shape[0], enc.shape[2]
         P = pool.P if pool is not None else enc.shape[1]
         T = max(decode_lengths)

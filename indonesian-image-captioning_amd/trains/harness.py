@@ -132,7 +132,7 @@ class TrainStep:
     def step(self, imgs, tags, caps, caplens, encoder_out=None, prepool=None):
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.encoder_bf16):
             if self.encoder is not None:
-                if self.kind in ("attention_scn", "pure_scn") and self.pooled_attention and self.encoder_call is self.encoder:
+                if self.pooled_attention and self.encoder_call is self.encoder:
                     prepool = self.encoder(imgs, pooled=False)     # the decoder works on the 8x8 source map
                     encoder_out = None
                 else:
@@ -151,7 +151,9 @@ class TrainStep:
                 pool_size=self.encoder.enc_image_size if self.encoder is not None else 14)
             alphas = None
         else:
-            scores, caps_sorted, decode_lengths, alphas, sort_ind = self.decoder(encoder_out, caps, caplens)
+            scores, caps_sorted, decode_lengths, alphas, sort_ind = self.decoder(
+                encoder_out, caps, caplens, prepool=prepool,
+                pool_size=self.encoder.enc_image_size if self.encoder is not None else 14)
         dl_dev = (caplens.reshape(-1)[sort_ind] - 1).to(torch.int32) if self.fused_loss else None
         loss = self.loss_fn(scores, caps_sorted, decode_lengths, alphas, dl_dev)
         self.decoder_optimizer.zero_grad()
