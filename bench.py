@@ -10,7 +10,7 @@ Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line
 
 Extra objects in the line (task contract):
   roofline     -- the per-timestep decode kernel group (the "fused SCN-cell + attention step" of
-                  north_star; 6 launches per step in this round): algorithmic bytes per step
+                  north_star; 7 launches per step in this round): algorithmic bytes per step
                   (enc + att1 + recurrent weights) / average step duration measured with
                   HIP events recorded by the library on the launch stream, against HBM peak 8 TB/s.
   cpu_baseline -- the CPU oracle (op-for-op restatement of the reference, oracle/scnattn_ref.py) timed
