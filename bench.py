@@ -187,6 +187,7 @@ def main():
     ap.add_argument("--dense-attention", action="store_true",
                     help="A/B: attention over the materialised 14x14 pooled map (the reference's data flow) instead "
                          "of the trunk's 8x8 source map (scnattn_pool)")
+    ap.add_argument("--bn-mask-from-y", action="store_true", help="A/B: BatchNorm backward reads y for the ReLU mask")
     ap.add_argument("--attn-depth", type=int, default=1, help="0: shallower load batches in attn_context/dalpha (A/B)")
     ap.add_argument("--gemm-opts", default="", help="diagnostics: target,kmin,kmin_small of the split-K policy")
     ap.add_argument("--graph", action="store_true", help="replay the encoder as HIP graphs (measured slower)")
@@ -214,6 +215,8 @@ def main():
     if args.ksplit:
         SF.set_option("ksplit", args.ksplit)
     SF.set_option("chains", args.chains)
+    if args.bn_mask_from_y:
+        SF.BN_MASK_FROM_Z = False
     if args.dense_attention:
         from models.decoders import _common as _dec_common
         _dec_common.USE_PREPOOL = False          # also ignore the map EncoderCaption attaches to its output

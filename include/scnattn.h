@@ -233,9 +233,12 @@ int scnattn_bn_stats(void* stream, int R, int C, const void* x, int bf16, float 
                      float* mean, float* invstd, float* run_mean, float* run_var);
 int scnattn_bn_apply(void* stream, int R, int C, const void* z, const void* res, int bf16, const float* mean,
                      const float* invstd, const float* gamma, const float* beta, int relu, void* y);
+/* relu != 0: the mask is [y > 0]; with y == NULL and beta given it is recomputed from z with the forward's own
+ * expression fma((z-mean)*invstd, gamma, beta) > 0 (only valid when no residual was added before the ReLU) and
+ * the backward pass never reads y. */
 int scnattn_bn_bwd(void* stream, int R, int C, const void* dy, const void* y, const void* z, int bf16,
-                   const float* mean, const float* invstd, const float* gamma, int relu, int train, float* partial,
-                   float* dbeta, float* dgamma, void* dz, void* dres);
+                   const float* mean, const float* invstd, const float* gamma, const float* beta, int relu, int train,
+                   float* partial, float* dbeta, float* dgamma, void* dz, void* dres);
 /* utils/optimizer.py:1-11 (element-wise clamp) fused with torch.optim.Adam's update
  * (trains/attention_scn.py:244-252); g is first scaled by gscale (1/world for data parallel). */
 int scnattn_clamp_adam(void* stream, long n, float* p, const float* g, float* m, float* v, double lr,

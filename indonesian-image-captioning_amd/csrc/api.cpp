@@ -245,9 +245,9 @@ int scnattn_bn_apply(void* stream, int R, int C, const void* z, const void* res,
 }
 
 int scnattn_bn_bwd(void* stream, int R, int C, const void* dy, const void* y, const void* z, int bf16,
-                   const float* mean, const float* invstd, const float* gamma, int relu, int train, float* partial,
-                   float* dbeta, float* dgamma, void* dz, void* dres) {
-    return bn_bwd(ST(stream), R, C, dy, y, z, bf16, mean, invstd, gamma, relu, train, partial, dbeta, dgamma, dz, dres);
+                   const float* mean, const float* invstd, const float* gamma, const float* beta, int relu, int train,
+                   float* partial, float* dbeta, float* dgamma, void* dz, void* dres) {
+    return bn_bwd(ST(stream), R, C, dy, y, z, bf16, mean, invstd, gamma, beta, relu, train, partial, dbeta, dgamma, dz, dres);
 }
 
 int scnattn_clamp_adam(void* stream, long n, float* p, const float* g, float* m, float* v, double lr,

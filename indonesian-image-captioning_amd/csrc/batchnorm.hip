@@ -168,11 +168,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(long n4, int C, const T* 
     }
 }
 
-// partial[chunk][2][C]: sum g, sum g*xhat, g = dy * [y > 0] (RELU) or dy
-template <typename T, bool RELU>
+// partial[chunk][2][C]: sum g, sum g*xhat, g = dy * [y > 0] (RELU) or dy.
+// MASKZ: the ReLU mask is recomputed from z with the forward's own expression, fma((z-mean)*invstd, gamma, beta) > 0,
+// instead of being read back from y -- valid when no residual was added before the ReLU (bn1/bn2 of a bottleneck);
+// the backward pass then never touches y (one 4-byte read per element less in each of its two passes).
+template <typename T, bool RELU, bool MASKZ>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(int R, int C, int rows_per_chunk, const T* __restrict__ dy,
                                                             const T* __restrict__ y, const T* __restrict__ z,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ partial) {
     __shared__ float red[16][2][64 + 1];
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
@@ -182,6 +186,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(int R, int C, int ro
     if (c < C) {
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
         const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c);
+        f32x4 ga = {0.f, 0.f, 0.f, 0.f}, be = {0.f, 0.f, 0.f, 0.f};
+        if (MASKZ) {
+            ga = *reinterpret_cast<const f32x4*>(gamma + c);
+            be = *reinterpret_cast<const f32x4*>(beta + c);
+        }
         for (int r = r0 + rl; r < r1; r += 32) {
             f32x4 g[2], yy[2], zz[2];
             bool ok[2];
@@ -192,17 +201,21 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(int R, int C, int ro
                 const long off = (long)min(rr, r1 - 1) * C + c;
                 g[j] = IO<T>::ld(dy + off);
                 zz[j] = IO<T>::ld(z + off);
-                if (RELU) yy[j] = IO<T>::ld(y + off);
+                if (RELU && !MASKZ) yy[j] = IO<T>::ld(y + off);
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     float gv = g[j][k];
-                    if (RELU && !(yy[j][k] > 0.f)) gv = 0.f;
+                    const float xh = (zz[j][k] - mu[k]) * is[k];
+                    if (RELU) {
+                        const bool on = MASKZ ? (fmaf(xh, ga[k], be[k]) > 0.f) : (yy[j][k] > 0.f);
+                        if (!on) gv = 0.f;
+                    }
                     if (!ok[j]) gv = 0.f;
                     sg[k] += gv;
-                    sx[k] = fmaf(gv, (zz[j][k] - mu[k]) * is[k], sx[k]);
+                    sx[k] = fmaf(gv, xh, sx[k]);
                 }
         }
     }
@@ -235,11 +248,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int C, int nchunk,
 }
 
 // TRAIN: dz = gamma*invstd*(g - dbeta/R - xhat*dgamma/R); eval: dz = gamma*invstd*g.  dres = g.
-template <typename T, bool RELU, bool TRAIN>
+template <typename T, bool RELU, bool TRAIN, bool MASKZ>
 __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(long n4, int R, int C, const T* __restrict__ dy,
                                                         const T* __restrict__ y, const T* __restrict__ z,
                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                        const float* __restrict__ gamma, const float* __restrict__ dbeta,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float* __restrict__ dbeta,
                                                         const float* __restrict__ dgamma, T* __restrict__ dz,
                                                         T* __restrict__ dres) {
     const int C4 = C >> 2;
@@ -247,18 +261,26 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(long n4, int R, int C, c
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const int c = (int)(i % C4) * 4;
         f32x4 g = IO<T>::ld(dy + i * 4);
-        if (RELU) {
+        const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
+        f32x4 zz = {0.f, 0.f, 0.f, 0.f}, mu = {0.f, 0.f, 0.f, 0.f};
+        if (TRAIN || MASKZ) {
+            zz = IO<T>::ld(z + i * 4);
+            mu = *reinterpret_cast<const f32x4*>(mean + c);
+        }
+        if (RELU && MASKZ) {
+            const f32x4 be = *reinterpret_cast<const f32x4*>(beta + c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (!(fmaf((zz[k] - mu[k]) * is[k], ga[k], be[k]) > 0.f)) g[k] = 0.f;
+        } else if (RELU) {
             const f32x4 yy = IO<T>::ld(y + i * 4);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (!(yy[k] > 0.f)) g[k] = 0.f;
         }
-        const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c);
-        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
         f32x4 o;
         if (TRAIN) {
-            const f32x4 zz = IO<T>::ld(z + i * 4);
-            const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
             const f32x4 db = *reinterpret_cast<const f32x4*>(dbeta + c);
             const f32x4 dg = *reinterpret_cast<const f32x4*>(dgamma + c);
 #pragma unroll
@@ -344,26 +366,30 @@ int bn_apply(hipStream_t st, int R, int C, const void* z, const void* res, int b
 
 template <typename T>
 static int bn_bwd_t(hipStream_t st, int R, int C, const T* dy, const T* y, const T* z, const float* mean,
-                    const float* invstd, const float* gamma, int relu, int train, float* partial, float* dbeta,
-                    float* dgamma, T* dz, T* dres) {
+                    const float* invstd, const float* gamma, const float* beta, int relu, int train, float* partial,
+                    float* dbeta, float* dgamma, T* dz, T* dres) {
     int rpc;
     const int nchunk = pick_chunks(R, C, &rpc);
     dim3 rgrid(cdiv(C, 64), nchunk), block(256);
-    if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), rgrid, block, 0, st, R, C, rpc, dy, y, z, mean, invstd, partial);
-    else      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), rgrid, block, 0, st, R, C, rpc, dy, y, z, mean, invstd, partial);
+    const bool maskz = relu && !y;       // ReLU mask recomputed from z (no residual in front of the ReLU)
+    if (maskz)     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true, true>), rgrid, block, 0, st, R, C, rpc, dy, y, z, mean, invstd, gamma, beta, partial);
+    else if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true, false>), rgrid, block, 0, st, R, C, rpc, dy, y, z, mean, invstd, gamma, beta, partial);
+    else           hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false, false>), rgrid, block, 0, st, R, C, rpc, dy, y, z, mean, invstd, gamma, beta, partial);
     SCN_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), block, 0, st, C, nchunk, partial, dbeta, dgamma);
     SCN_LAUNCH_CHECK();
     if (dz || dres) {
         const long n4 = (long)R * C / 4;
         dim3 grid(ew_blocks(n4));
-#define SCN_BN_DX(RELU_, TRAIN_)                                                                                     \
-    hipLaunchKernelGGL((bn_bwd_dx_kernel<T, RELU_, TRAIN_>), grid, block, 0, st, n4, R, C, dy, y, z, mean, invstd, gamma, \
-                       dbeta, dgamma, dz, dres)
-        if (relu && train) SCN_BN_DX(true, true);
-        else if (relu) SCN_BN_DX(true, false);
-        else if (train) SCN_BN_DX(false, true);
-        else SCN_BN_DX(false, false);
+#define SCN_BN_DX(RELU_, TRAIN_, MASKZ_)                                                                                  \
+    hipLaunchKernelGGL((bn_bwd_dx_kernel<T, RELU_, TRAIN_, MASKZ_>), grid, block, 0, st, n4, R, C, dy, y, z, mean, invstd, \
+                       gamma, beta, dbeta, dgamma, dz, dres)
+        if (maskz && train) SCN_BN_DX(true, true, true);
+        else if (maskz) SCN_BN_DX(true, false, true);
+        else if (relu && train) SCN_BN_DX(true, true, false);
+        else if (relu) SCN_BN_DX(true, false, false);
+        else if (train) SCN_BN_DX(false, true, false);
+        else SCN_BN_DX(false, false, false);
 #undef SCN_BN_DX
         SCN_LAUNCH_CHECK();
     }
@@ -371,15 +397,15 @@ static int bn_bwd_t(hipStream_t st, int R, int C, const T* dy, const T* y, const
 }
 
 int bn_bwd(hipStream_t st, int R, int C, const void* dy, const void* y, const void* z, int bf16, const float* mean,
-           const float* invstd, const float* gamma, int relu, int train, float* partial, float* dbeta, float* dgamma,
-           void* dz, void* dres) {
+           const float* invstd, const float* gamma, const float* beta, int relu, int train, float* partial, float* dbeta,
+           float* dgamma, void* dz, void* dres) {
     SCN_ARG(R > 0 && C > 0 && C % 4 == 0 && dy && z && mean && invstd && gamma && partial && dbeta && dgamma,
             "bn_bwd: bad argument");
-    SCN_ARG(!relu || y, "bn_bwd: relu needs the forward output");
-    if (bf16) return bn_bwd_t<__bf16>(st, R, C, (const __bf16*)dy, (const __bf16*)y, (const __bf16*)z, mean, invstd, gamma, relu, train,
-                                      partial, dbeta, dgamma, (__bf16*)dz, (__bf16*)dres);
-    return bn_bwd_t<float>(st, R, C, (const float*)dy, (const float*)y, (const float*)z, mean, invstd, gamma, relu, train, partial,
-                           dbeta, dgamma, (float*)dz, (float*)dres);
+    SCN_ARG(!relu || y || beta, "bn_bwd: relu needs the forward output y, or beta to recompute the mask from z");
+    if (bf16) return bn_bwd_t<__bf16>(st, R, C, (const __bf16*)dy, (const __bf16*)y, (const __bf16*)z, mean, invstd, gamma, beta, relu,
+                                      train, partial, dbeta, dgamma, (__bf16*)dz, (__bf16*)dres);
+    return bn_bwd_t<float>(st, R, C, (const float*)dy, (const float*)y, (const float*)z, mean, invstd, gamma, beta, relu, train,
+                           partial, dbeta, dgamma, (float*)dz, (float*)dres);
 }
 
 }  // namespace scn

@@ -131,7 +131,7 @@ int bn_stats(hipStream_t st, int R, int C, const void* x, int bf16, float eps, f
 int bn_apply(hipStream_t st, int R, int C, const void* z, const void* res, int bf16, const float* mean,
              const float* invstd, const float* gamma, const float* beta, int relu, void* y);
 int bn_bwd(hipStream_t st, int R, int C, const void* dy, const void* y, const void* z, int bf16, const float* mean,
-           const float* invstd, const float* gamma, int relu, int train, float* partial, float* dbeta, float* dgamma,
-           void* dz, void* dres);
+           const float* invstd, const float* gamma, const float* beta, int relu, int train, float* partial, float* dbeta,
+           float* dgamma, void* dz, void* dres);
 
 }  // namespace scn

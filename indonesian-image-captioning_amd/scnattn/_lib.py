@@ -82,7 +82,7 @@ _SIGS = {
     "scnattn_bn_workspace_floats": ([i32], i32),
     "scnattn_bn_stats": ([vp, i32, i32, vp, i32, f32, f32, vp, vp, vp, vp, vp], i32),
     "scnattn_bn_apply": ([vp, i32, i32, vp, vp, i32, vp, vp, vp, vp, i32, vp], i32),
-    "scnattn_bn_bwd": ([vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp], i32),
+    "scnattn_bn_bwd": ([vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp], i32),
     "scnattn_clamp_adam": ([vp, i64, vp, vp, vp, vp, f64, f64, f64, f64, i32, f64, f64], i32),
 }
 

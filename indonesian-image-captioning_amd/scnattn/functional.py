@@ -476,6 +476,7 @@ def pool_permute(x, out_size):
 # ----------------------------------------------------------------------------------------------
 # fused BatchNorm2d (+ residual) (+ ReLU), channels-last  (csrc/batchnorm.hip)
 # ----------------------------------------------------------------------------------------------
+BN_MASK_FROM_Z = True    # bn -> relu groups without residual: recompute the ReLU mask from z in the backward pass
 _bn_ws = {}
 _bn_fn = None
 
@@ -531,13 +532,17 @@ class _BNAct(torch.autograd.Function):
                      invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), int(relu), y.data_ptr())
         if rc:
             _lib.check(rc, "scnattn_bn_apply")
-        ctx.save_for_backward(z, y if relu else None, mean, invstd, gamma)
+        # bn -> relu without a residual in between (bn1/bn2 of a bottleneck), fp32: the backward pass recomputes the
+        # ReLU mask from z and never reads y
+        mask_from_z = BN_MASK_FROM_Z and bool(relu) and res is None and not bf16
+        ctx.save_for_backward(z, y if (relu and not mask_from_z) else None, mean, invstd, gamma,
+                              beta if mask_from_z else None)
         ctx.cfg = (bool(training), bool(relu), res is not None, bf16)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        z, y, mean, invstd, gamma = ctx.saved_tensors
+        z, y, mean, invstd, gamma, beta = ctx.saved_tensors
         training, relu, has_res, bf16 = ctx.cfg
         N, Cn, H, W = z.shape
         R = N * H * W
@@ -549,7 +554,8 @@ class _BNAct(torch.autograd.Function):
         dgb = torch.empty((2, Cn), device=z.device, dtype=torch.float32)
         _, _, f_bwd, raw_stream = _bn_fns()
         rc = f_bwd(raw_stream(z.device.index), R, Cn, dy.data_ptr(), None if y is None else y.data_ptr(), z.data_ptr(),
-                   bf16, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), int(relu), int(training),
+                   bf16, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), None if beta is None else beta.data_ptr(),
+                   int(relu), int(training),
                    _bn_workspace(z.device, Cn).data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
                    None if dz is None else dz.data_ptr(), None if dres is None else dres.data_ptr())
         if rc:
