@@ -333,3 +333,20 @@ def test_state_dict_checkpoint_feeds_the_reference_tooling_keys(tmp_path):
         assert torch.equal(a, b.cpu()), k
     t = save_state_dicts(str(tmp_path / "tagger.pth"), tagger=enc)
     assert set(torch.load(t, weights_only=True)) == {"model_state_dict"}
+
+
+def test_public_header_is_plain_c(tmp_path):
+    """include/scnattn.h is the drop-in boundary: it must compile as C99 on its own (plain pointers and sizes,
+    no C++ or torch types), and as C++."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "scnattn.h"\nint main(void) { scnattn_dims d; scnattn_params p; scnattn_pool q; '
+                   '(void)d; (void)p; (void)q; return 0; }\n')
+    inc = os.path.join(ROOT, "include")
+    for cmd in (["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)],
+                ["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", "-I", inc, str(src)]):
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=60)
+        assert out.returncode == 0, out.stderr
