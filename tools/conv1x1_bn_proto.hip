@@ -152,18 +152,147 @@ __global__ __launch_bounds__(256, 3) void conv1x1_kernel(int R, int Cin, int Cou
     }
 }
 
+// ---- variant 2: LDS layout [k&1][row][k>>1] for the k-contiguous operands ------------------------------------
+// lane (row, hh) of an MFMA operand needs k = kk + hh for kk = 0, 2, 4, ...: with this layout those 8 values of a
+// 16-k step are 32 contiguous bytes, so the fragment reads are two ds_read_b128 per 32-row tile per k-step instead of
+// eight ds_read_b32, and staging a thread's 4 consecutive k is two ds_write_b64 instead of four ds_write_b32.
+constexpr int KP = BK / 2;                     // 8 k-pairs per step; KPL = padded row length (8: none, 12: 48-byte rows)
+
+template <int KPL>
+__device__ __forceinline__ void store_tile_v2(float (*lds)[BM][KPL], int tid, const float (&reg)[2][4]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (tid >> 2) + 64 * i, q = (tid & 3) * 2;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<f32x2*>(&lds[0][r][q]) = f32x2{reg[i][0], reg[i][2]};
+        *reinterpret_cast<f32x2*>(&lds[1][r][q]) = f32x2{reg[i][1], reg[i][3]};
+    }
+}
+
+template <bool PRO, bool EPI, int KPL>
+__global__ __launch_bounds__(256, 3) void conv1x1_v2_kernel(int R, int Cin, int Cout, const float* __restrict__ Z,
+                                                            const float* __restrict__ W, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, float* __restrict__ Y,
+                                                            float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float As[2][2][BM][KPL];
+    __shared__ __attribute__((aligned(16))) float Bs[2][2][BN][KPL];
+    __shared__ float colsum[2][2][BN];
+    extern __shared__ float ss[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    if (PRO) {
+        for (int k = tid; k < Cin; k += 256) { ss[k] = scale[k]; ss[Cin + k] = shift[k]; }
+        __syncthreads();
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float ra[2][4], rb[2][4];
+    const int nk = (Cin + BK - 1) / BK;
+    const __amdgpu_buffer_rsrc_t ars = make_rsrc(Z, (unsigned)((long)R * Cin * 4));
+    const __amdgpu_buffer_rsrc_t brs = make_rsrc(W, (unsigned)((long)Cout * Cin * 4));
+    auto prologue = [&](float (&reg)[2][4], int k0) {
+        if (!PRO) return;
+        const int k = k0 + (tid & 3) * 4;
+        if (k >= Cin) return;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(ss + k);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(ss + Cin + k);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) reg[i][c] = fmaxf(fmaf(reg[i][c], sc[c], sh[c]), 0.f);
+    };
+    load_tile(ars, Cin, m0, 0, R, Cin, tid, ra);
+    load_tile(brs, Cin, n0, 0, Cout, Cin, tid, rb);
+    prologue(ra, 0);
+    store_tile_v2<KPL>(As[0], tid, ra);
+    store_tile_v2<KPL>(Bs[0], tid, rb);
+    __syncthreads();
+    const int hh = lane >> 5, l31 = lane & 31;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            load_tile(ars, Cin, m0, (kt + 1) * BK, R, Cin, tid, ra);
+            load_tile(brs, Cin, n0, (kt + 1) * BK, Cout, Cin, tid, rb);
+        }
+        f32x4 a[2][2], b[2][2];      // [tile][half of the 8 k-pairs]
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) a[i][h] = *reinterpret_cast<const f32x4*>(&As[cur][hh][wm * 64 + i * 32 + l31][4 * h]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) b[j][h] = *reinterpret_cast<const f32x4*>(&Bs[cur][hh][wn * 64 + j * 32 + l31][4 * h]);
+#pragma unroll
+        for (int p = 0; p < KP; ++p)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][p >> 2][p & 3], b[j][p >> 2][p & 3], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) {
+            prologue(ra, (kt + 1) * BK);
+            store_tile_v2<KPL>(As[cur ^ 1], tid, ra);
+            store_tile_v2<KPL>(Bs[cur ^ 1], tid, rb);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + l31;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + mfma32_row(r, lane);
+                const float v = acc[i][j][r];
+                if (n < Cout && m < R) {
+                    Y[(long)m * Cout + n] = v;
+                    s1 += v;
+                    s2 = fmaf(v, v, s2);
+                }
+            }
+        if (EPI) {
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lane < 32) { colsum[wm][0][wn * 64 + j * 32 + l31] = s1; colsum[wm][1][wn * 64 + j * 32 + l31] = s2; }
+        }
+    }
+    if (EPI) {
+        __syncthreads();
+        if (tid < BN && n0 + tid < Cout) {
+            float* p = partial + ((long)blockIdx.y * 2) * Cout + n0 + tid;
+            p[0] = colsum[0][0][tid] + colsum[1][0][tid];
+            p[Cout] = colsum[0][1][tid] + colsum[1][1][tid];
+        }
+    }
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
-template <bool PRO, bool EPI>
+template <bool PRO, bool EPI, int V = 1>
 float run(int R, int Cin, int Cout, const float* Z, const float* W, const float* sc, const float* sh, float* Y, float* part,
           int iters) {
     dim3 grid((Cout + BN - 1) / BN, (R + BM - 1) / BM), block(256);
     const size_t dyn = PRO ? 2 * Cin * sizeof(float) : 0;
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((conv1x1_kernel<PRO, EPI>), grid, block, dyn, 0, R, Cin, Cout, Z, W, sc, sh, Y, part);
+    auto launch = [&]() {
+        if (V == 2) hipLaunchKernelGGL((conv1x1_v2_kernel<PRO, EPI, 8>), grid, block, dyn, 0, R, Cin, Cout, Z, W, sc, sh, Y, part);
+        else if (V == 3) hipLaunchKernelGGL((conv1x1_v2_kernel<PRO, EPI, 12>), grid, block, dyn, 0, R, Cin, Cout, Z, W, sc, sh, Y, part);
+        else        hipLaunchKernelGGL((conv1x1_kernel<PRO, EPI>), grid, block, dyn, 0, R, Cin, Cout, Z, W, sc, sh, Y, part);
+    };
+    for (int i = 0; i < 3; ++i) launch();
     hipEvent_t a, b;
     CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     CK(hipEventRecord(a, 0));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv1x1_kernel<PRO, EPI>), grid, block, dyn, 0, R, Cin, Cout, Z, W, sc, sh, Y, part);
+    for (int i = 0; i < iters; ++i) launch();
     CK(hipEventRecord(b, 0));
     CK(hipEventSynchronize(b));
     float ms = 0;
@@ -176,7 +305,7 @@ int main() {
     struct Shape { const char* name; int R, Cin, Cout; };
     const Shape shapes[] = {{"l1.conv3", 131072, 64, 256}, {"l2.conv1", 32768, 512, 128}, {"l2.conv3", 32768, 128, 512},
                             {"l3.conv1", 8192, 1024, 256}, {"l3.conv3", 8192, 256, 1024}, {"l4.conv1", 2048, 2048, 512},
-                            {"l4.conv3", 2048, 512, 2048}};
+                            {"l4.conv3", 2048, 512, 2048}, {"sq4096", 4096, 4096, 4096}};
     printf("%-10s %8s %6s %6s | %9s %7s | %9s %7s | %9s %7s | check\n", "layer", "R", "Cin", "Cout", "plain us", "TF",
            "+pro us", "TF", "+pro+epi", "TF");
     for (const Shape& s : shapes) {
@@ -197,6 +326,9 @@ int main() {
         const float t0 = run<false, false>(s.R, s.Cin, s.Cout, Z, W, sc, sh, Y, part, 20);
         const float t1 = run<true, false>(s.R, s.Cin, s.Cout, Z, W, sc, sh, Y, part, 20);
         const float t2 = run<true, true>(s.R, s.Cin, s.Cout, Z, W, sc, sh, Y, part, 20);
+        const float w0 = run<false, false, 3>(s.R, s.Cin, s.Cout, Z, W, sc, sh, Y, part, 20);
+        const float u0 = run<false, false, 2>(s.R, s.Cin, s.Cout, Z, W, sc, sh, Y, part, 20);
+        const float u2 = run<true, true, 2>(s.R, s.Cin, s.Cout, Z, W, sc, sh, Y, part, 20);   // last run: checked below
         // check: a few outputs and one column's statistics of the prologue+epilogue run
         std::vector<float> hy(ny), hp((long)mt * 2 * s.Cout);
         CK(hipMemcpy(hy.data(), Y, ny * 4, hipMemcpyDeviceToHost));
@@ -216,8 +348,9 @@ int main() {
         for (long m = 0; m < s.R; ++m) cs += hy[m * s.Cout + n];
         for (int i = 0; i < mt; ++i) ps += hp[((long)i * 2) * s.Cout + n];
         const double serr = fabs(cs - ps) / (fabs(cs) + 1e-3);
-        printf("%-10s %8d %6d %6d | %9.1f %7.1f | %9.1f %7.1f | %9.1f %7.1f | out %.1e stats %.1e\n", s.name, s.R, s.Cin,
-               s.Cout, t0, flop / t0 / 1e6, t1, flop / t1 / 1e6, t2, flop / t2 / 1e6, worst, serr);
+        printf("%-10s %8d %6d %6d | %9.1f %7.1f | %9.1f %7.1f | %9.1f %7.1f | v2 plain %6.1f %6.1f  fused %6.1f %6.1f  pad12 plain %6.1f %6.1f | out %.1e stats %.1e\n",
+               s.name, s.R, s.Cin, s.Cout, t0, flop / t0 / 1e6, t1, flop / t1 / 1e6, t2, flop / t2 / 1e6, u0, flop / u0 / 1e6, u2,
+               flop / u2 / 1e6, w0, flop / w0 / 1e6, worst, serr);
         CK(hipFree(Z)); CK(hipFree(W)); CK(hipFree(sc)); CK(hipFree(sh)); CK(hipFree(Y)); CK(hipFree(part));
     }
     return 0;
