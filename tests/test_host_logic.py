@@ -350,3 +350,80 @@ def test_public_header_is_plain_c(tmp_path):
                 ["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", "-I", inc, str(src)]):
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=60)
         assert out.returncode == 0, out.stderr
+
+
+def test_synthetic_batch_follows_the_word_map_convention():
+    """SURVEY 8d / utils/dataset.py:302-306: <start> = V-2 at column 0, words in [1, V-4], <end> = V-1 closing the
+    caption, pad = 0 after it; caplens counts <start> and <end>; the ragged variant varies the lengths."""
+    from trains.harness import synthetic_batch, DEFAULTS
+    V, ml = 50, 10
+    imgs, tags, caps, caplens = synthetic_batch(6, V, ml, 16, 7, "cpu", 3)
+    assert imgs.shape == (6, 3, 16, 16) and tags.shape == (6, 7) and caps.shape == (6, ml + 2) and caplens.shape == (6, 1)
+    assert (caplens == ml + 2).all() and (caps[:, 0] == V - 2).all() and (caps[:, -1] == V - 1).all()
+    assert caps[:, 1:-1].min() >= 1 and caps[:, 1:-1].max() <= V - 4 and (0 <= tags).all() and (tags <= 1).all()
+    _, _, caps_r, lens_r = synthetic_batch(16, V, ml, 16, 7, "cpu", 3, ragged=True)
+    assert len(set(lens_r.flatten().tolist())) > 1
+    for c, n in zip(caps_r, lens_r.flatten().tolist()):
+        assert c[0] == V - 2 and c[n - 1] == V - 1 and (c[n:] == 0).all() and (c[1:n - 1] >= 1).all()
+    assert DEFAULTS["batch_size"] == 32 and DEFAULTS["decoder_lr"] == 4e-4 and DEFAULTS["encoder_lr"] == 1e-4 \
+        and DEFAULTS["grad_clip"] == 5.0 and DEFAULTS["alpha_c"] == 1.0 and DEFAULTS["dropout"] == 0.5   # trains/attention_scn.py:31-61
+
+
+def test_caption_files_and_metric_optimizer_helpers():
+    """scnattn.data.CaptionFiles on the h5py-written fixtures; utils.metric.{AverageMeter, accuracy} and
+    utils.optimizer.{clip_gradient, adjust_learning_rate} with the reference's semantics (utils/metric.py:1-39,
+    utils/optimizer.py:1-26)."""
+    from scnattn.data import CaptionFiles
+    from utils.metric import AverageMeter, accuracy
+    from utils.optimizer import clip_gradient, adjust_learning_rate
+    G = os.path.join(os.path.dirname(__file__), "golden", "hdf5")
+    cf = CaptionFiles(G, "tiny_2_cap_per_img_0_min_word_freq", "TRAIN", cpi=None)
+    assert cf.cpi == 2 and len(cf) == 6 and cf.imgs.shape == (3, 3, 256, 256) and cf.imgs.dtype == np.uint8
+    assert cf.captions.shape == (6, 8) and cf.caplens.shape == (6,) and not cf.imgs.flags.writeable
+    with pytest.raises(RuntimeError, match="need more than"):
+        CaptionFiles(G, "tiny_2_cap_per_img_0_min_word_freq", "TRAIN", cpi=1)        # 6 captions at 1 per image > 3 images
+    m = AverageMeter()
+    m.update(2.0, 3)
+    m.update(4.0, 1)
+    assert m.val == 4.0 and m.sum == 10.0 and m.count == 4 and m.avg == 2.5
+    scores = torch.tensor([[0.1, 0.9, 0.0], [0.8, 0.1, 0.1], [0.2, 0.3, 0.5]])
+    assert accuracy(scores, torch.tensor([1, 2, 2]), 1) == pytest.approx(100.0 * 2 / 3)
+    assert accuracy(scores, torch.tensor([1, 2, 2]), 2) == pytest.approx(100.0 * 2 / 3)
+    assert accuracy(scores, torch.tensor([1, 1, 2]), 2) == pytest.approx(100.0)
+    w = torch.nn.Parameter(torch.zeros(4))
+    opt = torch.optim.Adam([w], lr=4e-4)
+    w.grad = torch.tensor([-9.0, -1.0, 2.0, 7.0])
+    clip_gradient(opt, 5.0)
+    assert w.grad.tolist() == [-5.0, -1.0, 2.0, 5.0]
+    adjust_learning_rate(opt, 0.8)
+    assert opt.param_groups[0]["lr"] == pytest.approx(3.2e-4)
+
+
+def test_pure_attention_lstm_as_scn_relayout():
+    """PureAttention._scn_view_of_lstm: the SCN-shaped weights reproduce torch's LSTMCell pre-activations gate by
+    gate (torch order i, f, g, o -> SCN order i, f, o, c), the constant factors are ones / identities, and autograd
+    reaches the LSTMCell's own parameters through the re-layout."""
+    from models.decoders.pure_attention import PureAttention
+    from scnattn._lib import PARAM_FIELDS
+    torch.manual_seed(3)
+    m = PureAttention(8, 6, 5, 20, encoder_dim=12, dropout=0.0)
+    H, I = 5, 6 + 12
+    w = dict(zip(PARAM_FIELDS, m._scn_view_of_lstm()))
+    assert w["decode_step_weight_ia"].shape == (I, 4 * H) and w["decode_step_weight_ha"].shape == (H, 4 * H)
+    assert torch.equal(w["decode_step_weight_ib"], torch.ones(1, 4 * H))
+    assert torch.equal(w["decode_step_weight_ic"], torch.eye(H).repeat(1, 4))
+    u, h = torch.randn(3, I), torch.randn(3, H)
+    pre = u @ w["decode_step_weight_ia"] + w["decode_step_bias_ih"] + h @ w["decode_step_weight_ha"] + w["decode_step_bias_hh"]
+    cell = m.decode_step
+    ref = u @ cell.weight_ih.t() + cell.bias_ih + h @ cell.weight_hh.t() + cell.bias_hh       # torch blocks: i, f, g, o
+    i_, f_, g_, o_ = ref.split(H, dim=1)
+    assert torch.allclose(pre, torch.cat([i_, f_, o_, g_], dim=1), atol=1e-6)
+    c0 = torch.randn(3, H)
+    si, sf, so, sc = pre.split(H, dim=1)
+    c1 = torch.sigmoid(sf) * c0 + torch.sigmoid(si) * torch.tanh(sc)
+    h1 = torch.sigmoid(so) * torch.tanh(c1)
+    h_ref, c_ref = cell(u, (h, c0))
+    assert torch.allclose(h1, h_ref, atol=1e-6) and torch.allclose(c1, c_ref, atol=1e-6)
+    pre.sum().backward()
+    assert cell.weight_ih.grad is not None and cell.weight_hh.grad is not None and cell.bias_ih.grad.abs().sum() > 0
+    assert w["embedding_weight"] is m.embedding.weight and w["fc_weight"] is m.fc.weight
