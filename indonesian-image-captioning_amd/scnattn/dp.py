@@ -8,7 +8,6 @@ buckets are cut in flat order and fire as soon as every parameter in them has it
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): buckets are sized (default 32 MiB) so that a
 ring step moves MiB-sized chunks per link, and the division by world size is folded into the fused
 optimizer kernel (grad_scale) instead of a separate pass."""
-import torch
 import torch.distributed as dist
 
 

@@ -5,7 +5,6 @@ import math
 from collections import Counter
 from fractions import Fraction
 
-import torch
 
 
 class AverageMeter(object):
