@@ -82,10 +82,11 @@ def make_drop_mask(module, B, T, D, device):
     return torch.empty((B, T, D), device=device, dtype=torch.float32).bernoulli_(keep).div_(keep)
 
 
-def beam_search(decoder, beam_size, word_map, encoder_out, tag_out, use_attention, use_tags):
+def beam_search(decoder, beam_size, word_map, encoder_out, tag_out, use_attention, use_tags, return_all=False):
     """Beam search shared by AttentionSCN / PureSCN / PureAttention ``sample`` (reference
     attention_scn.py:160-296, pure_scn.py:142-249, pure_attention.py:153-281).  Identical control flow,
-    with the unrolled-index split done by FLOOR division (the reference's ``/`` breaks on torch >= 1.5)."""
+    with the unrolled-index split done by FLOOR division (the reference's ``/`` breaks on torch >= 1.5).
+    ``return_all`` (tests): also return every completed (sequence, score) pair in completion order."""
     k = beam_size
     vocab_size = len(word_map)
     dev = encoder_out.device
@@ -159,6 +160,7 @@ def beam_search(decoder, beam_size, word_map, encoder_out, tag_out, use_attentio
             complete_seqs_alpha = seqs_alpha.tolist()
     i = complete_seqs_scores.index(max(complete_seqs_scores))
     seq = complete_seqs[i]
-    if use_attention:
-        return seq, complete_seqs_alpha[i]
-    return seq
+    out = (seq, complete_seqs_alpha[i]) if use_attention else seq
+    if return_all:
+        return out, list(zip(complete_seqs, complete_seqs_scores))
+    return out

@@ -129,10 +129,14 @@ class TrainStep:
             loss = loss + self.cfg["alpha_c"] * ((1. - alphas.sum(dim=1)) ** 2).mean()
         return loss
 
-    def step(self, imgs, tags, caps, caplens, encoder_out=None, prepool=None):
+    def step(self, imgs, tags, caps, caplens, encoder_out=None, prepool=None, drop_in=False):
+        """`drop_in=True` is the reference's literal call sequence (trains/attention_scn.py:213-216):
+        `encoder_out = encoder(imgs)` materialises the (B,14,14,2048) map, `decoder(encoder_out, ...)` receives only
+        that tensor (and finds the trunk map EncoderCaption attached to it).  The default hands the trunk map over
+        explicitly and skips the pooling kernel and its 51 MB write."""
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.encoder_bf16):
             if self.encoder is not None:
-                if self.pooled_attention and self.encoder_call is self.encoder:
+                if self.pooled_attention and self.encoder_call is self.encoder and not drop_in:
                     prepool = self.encoder(imgs, pooled=False)     # the decoder works on the 8x8 source map
                     encoder_out = None
                 else:

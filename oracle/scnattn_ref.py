@@ -102,10 +102,20 @@ def scn_cell_forward(P: Params, pre: str, u: Tensor, s: Tensor,
 # --------------------------------------------------------------------------
 # models/attention.py:26-44
 # --------------------------------------------------------------------------
+RELU_PROBE = None   # tests: a list that collects min |att1 + att2| of every attention step (how far the
+                    # pre-activations stay from the ReLU's kink); never changes the arithmetic
+
+
+def _relu(x: Tensor) -> Tensor:
+    if RELU_PROBE is not None:
+        RELU_PROBE.append(float(x.detach().abs().min()))
+    return torch.relu(x)
+
+
 def attention_forward(P: Params, pre: str, enc: Tensor, h: Tensor) -> Tuple[Tensor, Tensor]:
     att1 = F.linear(enc, P[pre + "encoder_att.weight"], P[pre + "encoder_att.bias"])
     att2 = F.linear(h, P[pre + "decoder_att.weight"], P[pre + "decoder_att.bias"])
-    att = F.linear(torch.relu(att1 + att2.unsqueeze(1)),
+    att = F.linear(_relu(att1 + att2.unsqueeze(1)),
                    P[pre + "full_att.weight"], P[pre + "full_att.bias"]).squeeze(2)
     alpha = torch.softmax(att, dim=1)
     awe = (enc * alpha.unsqueeze(2)).sum(dim=1)
@@ -178,7 +188,7 @@ def attention_scn_forward(P: Params, enc: Tensor, tags: Tensor, caps: Tensor, ca
         bt = sum(l > t for l in dl)
         if hoist:
             att2 = F.linear(h[:bt], P["attention.decoder_att.weight"], P["attention.decoder_att.bias"])
-            att = F.linear(torch.relu(att1_all[:bt] + att2.unsqueeze(1)),
+            att = F.linear(_relu(att1_all[:bt] + att2.unsqueeze(1)),
                            P["attention.full_att.weight"], P["attention.full_att.bias"]).squeeze(2)
             alpha = torch.softmax(att, dim=1)
             awe = (enc[:bt] * alpha.unsqueeze(2)).sum(dim=1)

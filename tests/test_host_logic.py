@@ -427,3 +427,43 @@ def test_pure_attention_lstm_as_scn_relayout():
     pre.sum().backward()
     assert cell.weight_ih.grad is not None and cell.weight_hh.grad is not None and cell.bias_ih.grad.abs().sum() > 0
     assert w["embedding_weight"] is m.embedding.weight and w["fc_weight"] is m.fc.weight
+
+
+def test_bench_refuses_a_world_size_that_differs_from_gpus():
+    """`bench.py --gpus 8` under a 1-rank environment used to run one GPU and report n_gpus 1.
+    Now a rank whose WORLD_SIZE differs from --gpus exits with a message, before any GPU call."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "WORLD_SIZE=1 but --gpus 2" in r.stderr
+
+
+def test_bench_starts_its_own_ranks_when_launched_bare(monkeypatch):
+    """`python bench.py --gpus N` without WORLD_SIZE starts `python -m torch.distributed.run --nproc-per-node N
+    bench.py <same args>` as a child (never an exec) and exits with its status."""
+    import importlib
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, **kw):
+        seen["cmd"] = cmd
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as ei:
+        bench.main()
+    assert ei.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")

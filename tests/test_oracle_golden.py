@@ -161,3 +161,44 @@ def test_adaptive_pool_matrix_matches_torch():
     y = torch.einsum("ih,bchw,jw->bijc", U, x, U)
     _close(y, R.pool_permute(x, 14).numpy(), atol=1e-6)
     assert np.allclose(U.sum(1).numpy(), 1.0)
+
+
+@pytest.mark.parametrize("name,kind", [("attention_scn_odd", "attention_scn"), ("pure_scn_distinct", "pure_scn"),
+                                       ("pure_attention_distinct", "pure_attention")])
+def test_beam_search_oracle_is_stable_across_precisions(name, kind):
+    """oracle/beam_ref.py (the reference's sample() with `//`): on the golden weights, sharpened as the GPU test
+    does, fp32 and fp64 pick the same beams in the same completion order -- i.e. the discrete search is not decided
+    by rounding on these fixtures, so an fp32 HIP implementation can be compared with it sequence for sequence.
+    Structure: sequences start with <start>, end with <end>, completion scores are non-increasing per step."""
+    from oracle import beam_ref as BR
+    d = dict(load_golden(name))
+    V = d["p.embedding.weight"].shape[0]
+    d["p.fc.weight"] = d["p.fc.weight"] * 10.0
+    fb = d["p.fc.bias"].copy()
+    fb[V - 1] += 0.2
+    d["p.fc.bias"] = fb
+    wm = {"<pad>": 0, "<unk>": V - 3, "<start>": V - 2, "<end>": V - 1}
+    for i in range(1, V - 3):
+        wm["w%d" % i] = i
+    done = 0
+    for b in range(d["enc"].shape[0]):
+        for k in (1, 3, 5):
+            res = []
+            for dt in (torch.float32, torch.float64):
+                P = params_from(d, dtype=dt)
+                enc = t(d["enc"], dt)[b:b + 1]
+                tags = t(d["tags"], dt)[b:b + 1] if kind != "pure_attention" else None
+                try:
+                    out, allc = BR.beam_search(kind, P, k, wm, enc, tags, return_all=True)
+                except ValueError:
+                    res.append(None)
+                    continue
+                seq = out if kind == "pure_scn" else out[0]
+                assert seq[0] == V - 2 and seq[-1] == V - 1 and len(allc) <= k
+                assert all(s[0] == V - 2 and s[-1] == V - 1 for s, _ in allc)
+                if kind != "pure_scn":
+                    assert len(out[1]) == len(seq)
+                res.append([s for s, _ in allc])
+            assert res[0] == res[1], (b, k)
+            done += res[1] is not None
+    assert done >= 4
