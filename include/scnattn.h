@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SCNATTN_VERSION 101 /* 0.1.1: scnattn_pool argument of the sequence drivers */
+#define SCNATTN_VERSION 102 /* 0.1.2: scnattn_cgemm / scnattn_conv1x1_* / scnattn_bn_finalize */
 
 int scnattn_version(void);
 const char* scnattn_last_error(void);
@@ -239,6 +239,55 @@ int scnattn_bn_apply(void* stream, int R, int C, const void* z, const void* res,
 int scnattn_bn_bwd(void* stream, int R, int C, const void* dy, const void* y, const void* z, int bf16,
                    const float* mean, const float* invstd, const float* gamma, const float* beta, int relu, int train,
                    float* partial, float* dbeta, float* dgamma, void* dz, void* dres);
+/* ---- 1x1 convolutions of the ResNet-152 trunk as fused GEMMs (csrc/cgemm.hip) --------------------------------
+ * Replaces the `nn.Conv2d(kernel_size=1)` layers of torchvision's Bottleneck (conv1, conv3, downsample.0) behind
+ * models/encoders/caption.py:17-22 -- forward, d input, d weight -- on channels-last maps, where such a convolution
+ * is the product [R = N*Ho*Wo, Cin] x [Cin, Cout], together with the BatchNorm work that can ride on it:
+ *   pro_ss [Cin][2] = {scale, shift} (fwd, wgrad): the input operand is taken as relu(x * scale[c] + shift[c]) --
+ *       the previous BatchNorm + ReLU folded to one fma per element (scale = gamma*invstd, shift = beta - mean*scale,
+ *       written interleaved by scnattn_bn_finalize) -- so the normalised map is never written to or read from HBM;
+ *   stat_partial [scnattn_cgemm_row_tiles(R)][2][Cout] (fwd): per 128-row tile and output channel, sum(y - s) and
+ *       sum((y - s)^2) with s = stat_shift[c] (or 0): the statistics pass of the NEXT BatchNorm, fixed order;
+ *   ez / emean / einvstd / egamma / ebeta (dgrad): the result is masked with the ReLU mask recomputed from the
+ *       BatchNorm input z ([R][Cin], leading dimension ldz), g = dx * [fma((z-mean)*invstd, gamma, beta) > 0], and
+ *       stat_partial receives sum(g), sum(g * xhat): the two reductions of that BatchNorm's backward pass.
+ * stride > 1 (downsample.0): input rows are gathered / scattered at (n, ho*stride, wo*stride) of an Hi x Wi map.
+ * ws / ws_floats: split-K partial sums (shapes whose 128x128 tile grid cannot fill the chip); may be NULL. */
+typedef struct scnattn_conv_extra {
+    int pro;                  /* 0 none, 1: A operand prologue (per k), 2: B operand prologue (per n) */
+    int epi;                  /* 0 plain, 1: statistics of the output, 2: ReLU mask from z + BatchNorm-backward sums */
+    const float* pro_ss;
+    float* stat_partial; const float* stat_shift;
+    const float* ez; const float* emean; const float* einvstd; const float* egamma; const float* ebeta; long ldz;
+    int stride, Hi, Wi, Ho, Wo;
+    int force_split;          /* > 0: force the split-K factor (tests, tuning) */
+} scnattn_conv_extra;
+/* C = alpha*op(A).op(B) + beta*C + bias, rows with rowmask == 0 written as 0: same contract as scnattn_sgemm_ws, on
+ * the LDS-DMA pipelined kernel; needs 16-byte aligned operands (returns -1 otherwise; scnattn_sgemm_ws picks the
+ * kernel by itself).  ex may be NULL. */
+int scnattn_cgemm(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, long lda,
+                  const float* B, long ldb, float beta, float* C, long ldc, const float* bias, const float* rowmask,
+                  int batch, long strideA, long strideB, long strideC, float* ws, long ws_floats,
+                  const scnattn_conv_extra* ex);
+int scnattn_cgemm_row_tiles(int M);
+/* y [R][Cout] = f(x) . w^T, w [Cout][Cin] (a channels-last 1x1 conv weight); R = output rows */
+int scnattn_conv1x1_fwd(void* stream, int R, int Cin, int Cout, const float* x, const float* w, float* y,
+                        const scnattn_conv_extra* ex, float* ws, long ws_floats);
+/* dx [R][Cin] = dy [R][Cout] . w (+ beta * dx: the residual branch's gradient is accumulated in place) */
+int scnattn_conv1x1_dgrad(void* stream, int R, int Cin, int Cout, const float* dy, const float* w, float beta,
+                          float* dx, const scnattn_conv_extra* ex, float* ws, long ws_floats);
+/* dw [Cout][Cin] = dy^T . f(x) */
+int scnattn_conv1x1_wgrad(void* stream, int R, int Cin, int Cout, const float* dy, const float* x, float* dw,
+                          const scnattn_conv_extra* ex, float* ws, long ws_floats);
+/* BatchNorm statistics from partial[nchunk][2][C] = {sum(x - s), sum((x - s)^2)} (s = shift[c] or 0), as written by
+ * the statistics epilogue above: mean, 1/sqrt(var+eps), running-stat update (momentum; run_* may be NULL), and, when
+ * ss_out is given, the folded {scale = gamma*invstd, shift = beta - mean*scale} pairs [C][2] for a consumer's prologue. */
+int scnattn_bn_finalize(void* stream, long R, int C, int nchunk, const float* partial, const float* shift, float eps,
+                        float momentum, float* mean, float* invstd, float* run_mean, float* run_var,
+                        const float* gamma, const float* beta, float* ss_out);
+/* dbeta[c] = sum_chunks partial[.][0][c], dgamma[c] = sum_chunks partial[.][1][c] (the mask epilogue's sums) */
+int scnattn_bn_bwd_finalize(void* stream, int C, int nchunk, const float* partial, float* dbeta, float* dgamma);
+
 /* utils/optimizer.py:1-11 (element-wise clamp) fused with torch.optim.Adam's update
  * (trains/attention_scn.py:244-252); g is first scaled by gscale (1/world for data parallel). */
 int scnattn_clamp_adam(void* stream, long n, float* p, const float* g, float* m, float* v, double lr,

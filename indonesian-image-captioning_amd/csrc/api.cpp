@@ -24,7 +24,7 @@ extern int g_profile;
 extern int g_fuse_attn;
 extern int g_chains;
 extern int g_attn_depth;
-extern int g_gemm_target, g_gemm_kmin, g_gemm_kmin_small, g_gemm_gate;
+extern int g_gemm_target, g_gemm_kmin, g_gemm_kmin_small, g_gemm_gate, g_use_cgemm, g_cgemm_target, g_cgemm_kmin;
 int profile_collect(double* out);
 int seq_workspace(const scnattn_dims* d, const scnattn_pool* pool, size_t* saved_bytes, size_t* scratch_bytes);
 int seq_fwd(hipStream_t st, const scnattn_dims* d, const scnattn_params* w, const float* enc, const float* tags,
@@ -64,6 +64,9 @@ int scnattn_set_option(const char* name, int value) {
     if (name && std::strcmp(name, "gemm_gate") == 0 && value >= 1) { g_gemm_gate = value; return 0; }
     if (name && std::strcmp(name, "gemm_kmin") == 0 && value >= 16) { g_gemm_kmin = value; return 0; }
     if (name && std::strcmp(name, "gemm_kmin_small") == 0 && value >= 16) { g_gemm_kmin_small = value; return 0; }
+    if (name && std::strcmp(name, "use_cgemm") == 0) { g_use_cgemm = value != 0; return 0; }
+    if (name && std::strcmp(name, "cgemm_target") == 0 && value >= 1) { g_cgemm_target = value; return 0; }
+    if (name && std::strcmp(name, "cgemm_kmin") == 0 && value >= 16) { g_cgemm_kmin = value; return 0; }
     if (name && std::strcmp(name, "profile") == 0) {
         g_profile = value;
         return 0;
@@ -110,6 +113,63 @@ int scnattn_sgemm_ws(void* stream, int transA, int transB, int M, int N, int K, 
                      long ws_floats) {
     return sgemm_ws(ST(stream), transA != 0, transB != 0, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, rowmask,
                     batch < 1 ? 1 : batch, strideA, strideB, strideC, ws, ws ? ws_floats : 0);
+}
+
+static ConvExtra to_extra(const scnattn_conv_extra* e) {
+    ConvExtra x;
+    if (!e) return x;
+    x.pro = e->pro; x.epi = e->epi; x.pro_ss = e->pro_ss;
+    x.stat_partial = e->stat_partial; x.stat_shift = e->stat_shift;
+    x.ez = e->ez; x.emean = e->emean; x.einvstd = e->einvstd; x.egamma = e->egamma; x.ebeta = e->ebeta; x.ldz = e->ldz;
+    x.stride = e->stride < 1 ? 1 : e->stride; x.Hi = e->Hi; x.Wi = e->Wi; x.Ho = e->Ho; x.Wo = e->Wo;
+    x.force_split = e->force_split;
+    return x;
+}
+
+int scnattn_cgemm(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, long lda,
+                  const float* B, long ldb, float beta, float* C, long ldc, const float* bias, const float* rowmask,
+                  int batch, long strideA, long strideB, long strideC, float* ws, long ws_floats,
+                  const scnattn_conv_extra* ex) {
+    const ConvExtra x = to_extra(ex);
+    return cgemm(ST(stream), transA != 0, transB != 0, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, rowmask,
+                 batch < 1 ? 1 : batch, strideA, strideB, strideC, ws, ws ? ws_floats : 0, ex ? &x : nullptr);
+}
+
+int scnattn_cgemm_row_tiles(int M) { return cgemm_row_tiles(M); }
+
+int scnattn_conv1x1_fwd(void* stream, int R, int Cin, int Cout, const float* x, const float* w, float* y,
+                        const scnattn_conv_extra* ex, float* ws, long ws_floats) {
+    const ConvExtra e = to_extra(ex);
+    SCN_ARG(!ex || ex->pro != 2, "conv1x1_fwd: prologue must be on the input (pro = 1)");
+    return cgemm(ST(stream), false, true, R, Cout, Cin, 1.f, x, Cin, w, Cin, 0.f, y, Cout, nullptr, nullptr, 1, 0, 0, 0,
+                 ws, ws ? ws_floats : 0, ex ? &e : nullptr);
+}
+
+int scnattn_conv1x1_dgrad(void* stream, int R, int Cin, int Cout, const float* dy, const float* w, float beta,
+                          float* dx, const scnattn_conv_extra* ex, float* ws, long ws_floats) {
+    const ConvExtra e = to_extra(ex);
+    SCN_ARG(!ex || (ex->pro == 0 && ex->stride <= 1), "conv1x1_dgrad: no prologue / stride here");
+    return cgemm(ST(stream), false, false, R, Cin, Cout, 1.f, dy, Cout, w, Cin, beta, dx, Cin, nullptr, nullptr, 1, 0, 0,
+                 0, ws, ws ? ws_floats : 0, ex ? &e : nullptr);
+}
+
+int scnattn_conv1x1_wgrad(void* stream, int R, int Cin, int Cout, const float* dy, const float* x, float* dw,
+                          const scnattn_conv_extra* ex, float* ws, long ws_floats) {
+    ConvExtra e = to_extra(ex);
+    SCN_ARG(!ex || (ex->pro != 1 && ex->epi == 0), "conv1x1_wgrad: prologue must be on the input (pro = 2), no epilogue");
+    return cgemm(ST(stream), true, false, Cout, Cin, R, 1.f, dy, Cout, x, Cin, 0.f, dw, Cin, nullptr, nullptr, 1, 0, 0, 0,
+                 ws, ws ? ws_floats : 0, ex ? &e : nullptr);
+}
+
+int scnattn_bn_finalize(void* stream, long R, int C, int nchunk, const float* partial, const float* shift, float eps,
+                        float momentum, float* mean, float* invstd, float* run_mean, float* run_var,
+                        const float* gamma, const float* beta, float* ss_out) {
+    return bn_finalize(ST(stream), R, C, nchunk, partial, shift, eps, momentum, mean, invstd, run_mean, run_var, gamma,
+                       beta, ss_out);
+}
+
+int scnattn_bn_bwd_finalize(void* stream, int C, int nchunk, const float* partial, float* dbeta, float* dgamma) {
+    return bn_bwd_finalize(ST(stream), C, nchunk, partial, dbeta, dgamma);
 }
 
 int scnattn_skinny_gemm(void* stream, int rows, int N, int K, int groups, const float* X, long ldx, long xg,

@@ -141,6 +141,39 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(int R, int C, int nchu
     }
 }
 
+// Same as bn_finalize_kernel for partials written by a GEMM statistics epilogue (shift vector instead of x[0][c]),
+// plus the folded scale/shift a consumer's prologue applies.
+__global__ __launch_bounds__(256) void bn_finalize_shift_kernel(long R, int C, int nchunk, const float* __restrict__ partial,
+                                                                const float* __restrict__ shift, float eps, float momentum,
+                                                                float* __restrict__ mean, float* __restrict__ invstd,
+                                                                float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float* __restrict__ ss_out) {
+    __shared__ float red[16][2][17];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), lane16 = threadIdx.x >> 4;
+    float s1, s2;
+    reduce_partials16(partial, C, nchunk, c, lane16, red, s1, s2);
+    if (lane16 != 0 || c >= C) return;
+    const float inv_n = 1.f / (float)R;
+    const float m1 = s1 * inv_n;
+    const float mu = (shift ? shift[c] : 0.f) + m1;
+    float var = s2 * inv_n - m1 * m1;
+    if (var < 0.f) var = 0.f;
+    const float is = rsqrtf(var + eps);
+    mean[c] = mu;
+    invstd[c] = is;
+    if (run_mean) run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mu;
+    if (run_var) {
+        const float unbiased = R > 1 ? var * ((float)R / (float)(R - 1)) : var;
+        run_var[c] = (1.f - momentum) * run_var[c] + momentum * unbiased;
+    }
+    if (ss_out) {
+        const float sc = gamma[c] * is;
+        ss_out[2 * c] = sc;
+        ss_out[2 * c + 1] = fmaf(-mu, sc, beta[c]);
+    }
+}
+
 template <typename T, bool RELU, bool RES>
 __global__ __launch_bounds__(256) void bn_apply_kernel(long n4, int C, const T* __restrict__ z,
                                                        const T* __restrict__ res, const float* __restrict__ mean,
@@ -319,6 +352,24 @@ inline unsigned ew_blocks(long n4) {
 }  // namespace
 
 int bn_max_chunks() { return 256; }
+
+int bn_finalize(hipStream_t st, long R, int C, int nchunk, const float* partial, const float* shift, float eps,
+                float momentum, float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma,
+                const float* beta, float* ss_out) {
+    SCN_ARG(R > 0 && C > 0 && nchunk > 0 && partial && mean && invstd, "bn_finalize: bad argument");
+    SCN_ARG(!ss_out || (gamma && beta), "bn_finalize: folded scale/shift need gamma and beta");
+    hipLaunchKernelGGL(bn_finalize_shift_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, R, C, nchunk, partial, shift, eps,
+                       momentum, mean, invstd, run_mean, run_var, gamma, beta, ss_out);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
+int bn_bwd_finalize(hipStream_t st, int C, int nchunk, const float* partial, float* dbeta, float* dgamma) {
+    SCN_ARG(C > 0 && nchunk > 0 && partial && dbeta && dgamma, "bn_bwd_finalize: bad argument");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, C, nchunk, partial, dbeta, dgamma);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
 
 template <typename T>
 static int bn_stats_t(hipStream_t st, int R, int C, const T* x, float eps, float momentum, float* partial, float* mean,

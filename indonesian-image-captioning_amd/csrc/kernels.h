@@ -19,6 +19,25 @@ int sgemm_ws(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha,
              const float* B, long ldb, float beta, float* C, long ldc, const float* bias, const float* rowmask,
              int batch, long sA, long sB, long sC, float* ws, long ws_floats);
 
+// ---- cgemm.hip: LDS-DMA pipelined fp32 GEMM with the 1x1-convolution prologues / epilogues -------------------
+struct ConvExtra {
+    int pro = 0;              // 1: A = relu(A*scale[k]+shift[k]) (k-contiguous A); 2: B = relu(B*scale[n]+shift[n]) ([K][N] B)
+    int epi = 0;              // 1: column sums of (y-s), (y-s)^2 per 128-row tile; 2: relu mask from z + sums of g, g*xhat
+    const float* pro_ss = nullptr;    // interleaved {scale, shift} per channel
+    float* stat_partial = nullptr;    // [row tiles][2][N]
+    const float* stat_shift = nullptr;
+    const float* ez = nullptr; const float* emean = nullptr; const float* einvstd = nullptr;
+    const float* egamma = nullptr; const float* ebeta = nullptr; long ldz = 0;
+    int stride = 1, Hi = 0, Wi = 0, Ho = 0, Wo = 0;   // stride > 1: rows of the activation operand are gathered
+    int force_split = 0;      // tests / tuning: > 0 forces the split-K factor
+};
+bool cgemm_supported(bool tA, bool tB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
+                     long sA, long sB);
+int cgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, const float* A, long lda, const float* B,
+          long ldb, float beta, float* C, long ldc, const float* bias, const float* rowmask, int batch, long sA, long sB,
+          long sC, float* ws, long ws_floats, const ConvExtra* ex);
+int cgemm_row_tiles(int M);
+
 // ---- skinny.hip ------------------------------------------------------------------------------
 int skinny_pick_ksplit(int rows, int N, int K, int groups);
 int skinny_gemm(hipStream_t st, int rows, int N, int K, int groups, const float* X, long ldx, long xg,
@@ -133,5 +152,11 @@ int bn_apply(hipStream_t st, int R, int C, const void* z, const void* res, int b
 int bn_bwd(hipStream_t st, int R, int C, const void* dy, const void* y, const void* z, int bf16, const float* mean,
            const float* invstd, const float* gamma, const float* beta, int relu, int train, float* partial, float* dbeta,
            float* dgamma, void* dz, void* dres);
+
+// statistics from partial[nchunk][2][C] (the GEMM epilogues of cgemm.hip), any nchunk
+int bn_finalize(hipStream_t st, long R, int C, int nchunk, const float* partial, const float* shift, float eps,
+                float momentum, float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma,
+                const float* beta, float* ss_out);
+int bn_bwd_finalize(hipStream_t st, int C, int nchunk, const float* partial, float* dbeta, float* dgamma);
 
 }  // namespace scn

@@ -215,6 +215,7 @@ int g_gemm_gate = 256;        // split only when the tile grid alone has fewer w
 int g_gemm_target = 512;      // aim for this many workgroups (tiles x splits)
 int g_gemm_kmin = 256;        // at least this much K per split ...
 int g_gemm_kmin_small = 128;  // ... or this much when the product has <= 16 tiles (32-row operands)
+int g_use_cgemm = 1;          // 16-byte-aligned products go to the LDS-DMA pipelined kernel of cgemm.hip
 
 int sgemm_ws(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, const float* A, long lda,
              const float* B, long ldb, float beta, float* C, long ldc, const float* bias, const float* rowmask,
@@ -222,6 +223,9 @@ int sgemm_ws(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha,
     if (M <= 0 || N <= 0 || batch <= 0) return 0;
     SCN_ARG(A && B && C, "sgemm: null operand");
     SCN_ARG(K >= 1, "sgemm: K must be >= 1");
+    if (g_use_cgemm && cgemm_supported(tA, tB, M, N, K, A, lda, B, ldb, sA, sB))
+        return cgemm(st, tA, tB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, rowmask, batch, sA, sB, sC, ws,
+                     ws_floats, nullptr);
     {
         const long abytes = (tA ? ((long)(K - 1) * lda + M) : ((long)(M - 1) * lda + K)) * 4;
         const long bbytes = (tB ? ((long)(N - 1) * ldb + K) : ((long)(K - 1) * ldb + N)) * 4;

@@ -45,6 +45,14 @@ class Pool(C.Structure):      # scnattn_pool
                 ("qtap_idx", C.c_void_p), ("qtap_w", C.c_void_p), ("col_w", C.c_void_p)]
 
 
+class ConvExtra(C.Structure):      # scnattn_conv_extra
+    _fields_ = [("pro", C.c_int), ("epi", C.c_int), ("pro_ss", C.c_void_p),
+                ("stat_partial", C.c_void_p), ("stat_shift", C.c_void_p), ("ez", C.c_void_p), ("emean", C.c_void_p),
+                ("einvstd", C.c_void_p), ("egamma", C.c_void_p), ("ebeta", C.c_void_p), ("ldz", C.c_long),
+                ("stride", C.c_int), ("Hi", C.c_int), ("Wi", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int),
+                ("force_split", C.c_int)]
+
+
 _SIGS = {
     "scnattn_version": ([], i32),
     "scnattn_set_option": ([C.c_char_p, i32], i32),
@@ -57,6 +65,14 @@ _SIGS = {
     "scnattn_sgemm": ([vp, i32, i32, i32, i32, i32, f32, vp, i64, vp, i64, f32, vp, i64, vp, vp, i32, i64, i64, i64], i32),
     "scnattn_sgemm_ws": ([vp, i32, i32, i32, i32, i32, f32, vp, i64, vp, i64, f32, vp, i64, vp, vp, i32, i64, i64, i64,
                           vp, i64], i32),
+    "scnattn_cgemm": ([vp, i32, i32, i32, i32, i32, f32, vp, i64, vp, i64, f32, vp, i64, vp, vp, i32, i64, i64, i64,
+                       vp, i64, C.POINTER(ConvExtra)], i32),
+    "scnattn_cgemm_row_tiles": ([i32], i32),
+    "scnattn_conv1x1_fwd": ([vp, i32, i32, i32, vp, vp, vp, C.POINTER(ConvExtra), vp, i64], i32),
+    "scnattn_conv1x1_dgrad": ([vp, i32, i32, i32, vp, vp, f32, vp, C.POINTER(ConvExtra), vp, i64], i32),
+    "scnattn_conv1x1_wgrad": ([vp, i32, i32, i32, vp, vp, vp, C.POINTER(ConvExtra), vp, i64], i32),
+    "scnattn_bn_finalize": ([vp, i64, i32, i32, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp], i32),
+    "scnattn_bn_bwd_finalize": ([vp, i32, i32, vp, vp, vp], i32),
     "scnattn_skinny_gemm": ([vp, i32, i32, i32, i32, vp, i64, i64, vp, i64, i64, vp, i64, i64, i64, i32,
                              C.POINTER(i32)], i32),
     "scnattn_attn_scores": ([vp, i32, i32, i32, vp, vp, i32, i64, i64, vp, vp, vp, vp, vp], i32),

@@ -1,0 +1,179 @@
+"""csrc/cgemm.hip on the ResNet-152 1x1-convolution shapes (B=32, 256x256 input) and the decoder's dense products:
+correctness against fp64 torch on every variant (plain / prologue / statistics epilogue / mask epilogue / split-K /
+strided gather), then time per launch against the round-1 sgemm kernel and MIOpen (torch conv, channels-last,
+cudnn.benchmark + FAST find).  Usage: python tools/cgemm_bench.py [check|time|all]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "indonesian-image-captioning_amd")); sys.path.insert(0, ROOT)
+os.environ.setdefault("MIOPEN_FIND_MODE", "2"); os.environ.setdefault("MIOPEN_LOG_LEVEL", "3")
+import torch
+import torch.nn.functional as F
+from scnattn import functional as SF
+from scnattn._lib import call, ptr, stream_of, ConvExtra, lib
+
+torch.backends.cudnn.benchmark = True
+dev = torch.device("cuda:0")
+WS = torch.empty(16 << 20, device=dev)
+
+
+def t_us(fn, it=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(it):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e3 / it
+
+
+def cgemm(a, b, ta, tb, out, M, N, K, ex=None, beta=0.0, ws=True):
+    call("scnattn_cgemm", stream_of(a), int(ta), int(tb), M, N, K, 1.0, ptr(a), a.stride(0), ptr(b), b.stride(0), beta,
+         ptr(out), out.stride(0), None, None, 1, 0, 0, 0, ptr(WS) if ws else None, WS.numel() if ws else 0,
+         None if ex is None else C.byref(ex))
+    return out
+
+
+def rel(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
+
+
+def check():
+    g = torch.Generator(device="cpu").manual_seed(0)
+    worst = 0.0
+    for (R, Cin, Cout) in [(2048, 512, 2048), (8192, 1024, 256), (2048, 64, 256), (300, 48, 72), (4096, 256, 64)]:
+        x = torch.randn(R, Cin, generator=g).to(dev); w = (torch.randn(Cout, Cin, generator=g) * 0.1).to(dev)
+        dy = torch.randn(R, Cout, generator=g).to(dev)
+        sc = (1 + 0.5 * torch.randn(Cin, generator=g)).to(dev); sh = (0.2 * torch.randn(Cin, generator=g)).to(dev)
+        ss = torch.stack([sc, sh], dim=1).contiguous()
+        xd, wd, dyd = x.double(), w.double(), dy.double()
+        for split in (0, 1, 2, 4):
+            if split > 1 and Cin // split < 16:
+                continue
+            # fwd plain
+            ex = ConvExtra(force_split=split)
+            y = cgemm(x, w, False, True, torch.empty(R, Cout, device=dev), R, Cout, Cin, ex)
+            e = rel(y, xd @ wd.t()); worst = max(worst, e); assert e < 3e-6, ("fwd", R, Cin, Cout, split, e)
+            # fwd prologue + stats epilogue
+            mt = lib().scnattn_cgemm_row_tiles(R)
+            part = torch.full((mt, 2, Cout), float("nan"), device=dev)
+            sft = (0.1 * torch.randn(Cout, generator=g)).to(dev)
+            ex = ConvExtra(pro=1, epi=1, pro_ss=ss.data_ptr(), stat_partial=part.data_ptr(),
+                           stat_shift=sft.data_ptr(), force_split=split)
+            y = cgemm(x, w, False, True, torch.empty(R, Cout, device=dev), R, Cout, Cin, ex)
+            a_ref = torch.relu(xd * sc.double() + sh.double())
+            y_ref = a_ref @ wd.t()
+            e = rel(y, y_ref); worst = max(worst, e); assert e < 3e-6, ("fwd pro", R, Cin, Cout, split, e)
+            d = y_ref - sft.double()
+            e1 = rel(part[:, 0].double().sum(0), d.sum(0)); e2 = rel(part[:, 1].double().sum(0), (d * d).sum(0))
+            assert e1 < 2e-5 and e2 < 2e-5, ("stats", R, Cin, Cout, split, e1, e2)
+            # dgrad plain + beta
+            dx0 = torch.randn(R, Cin, generator=g).to(dev)
+            dx = cgemm(dy, w, False, False, dx0.clone(), R, Cin, Cout, ConvExtra(force_split=split), beta=1.0)
+            e = rel(dx, dyd @ wd + dx0.double()); worst = max(worst, e); assert e < 3e-6, ("dgrad", R, Cin, Cout, split, e)
+            # dgrad mask epilogue
+            if Cin % 4 == 0:
+                z = torch.randn(R, Cin, generator=g).to(dev)
+                mu = (0.1 * torch.randn(Cin, generator=g)).to(dev); isd = (1 + 0.2 * torch.rand(Cin, generator=g)).to(dev)
+                ga = (1 + 0.3 * torch.randn(Cin, generator=g)).to(dev); be = (0.2 * torch.randn(Cin, generator=g)).to(dev)
+                part = torch.full((mt, 2, Cin), float("nan"), device=dev)
+                ex = ConvExtra(epi=2, stat_partial=part.data_ptr(), ez=z.data_ptr(), emean=mu.data_ptr(), einvstd=isd.data_ptr(),
+                               egamma=ga.data_ptr(), ebeta=be.data_ptr(), ldz=Cin, force_split=split)
+                gk = cgemm(dy, w, False, False, torch.empty(R, Cin, device=dev), R, Cin, Cout, ex)
+                xh = (z - mu) * isd
+                mask = (torch.addcmul(be, xh, ga) > 0)
+                g_ref = (dyd @ wd) * mask.double()
+                e = rel(gk, g_ref); assert e < 3e-6, ("dgrad mask", R, Cin, Cout, split, e)
+                e1 = rel(part[:, 0].double().sum(0), g_ref.sum(0)); e2 = rel(part[:, 1].double().sum(0), (g_ref * xh.double()).sum(0))
+                assert e1 < 2e-5 and e2 < 2e-5, ("mask stats", R, Cin, Cout, split, e1, e2)
+            # wgrad plain and with the B prologue
+            if Cout % 4 == 0 and Cin % 4 == 0 and (split <= 1 or R // split >= 16):
+                dw = cgemm(dy, x, True, False, torch.empty(Cout, Cin, device=dev), Cout, Cin, R, ConvExtra(force_split=split))
+                e = rel(dw, dyd.t() @ xd); worst = max(worst, e); assert e < 1e-5, ("wgrad", R, Cin, Cout, split, e)
+                ex = ConvExtra(pro=2, pro_ss=ss.data_ptr(), force_split=split)
+                dw = cgemm(dy, x, True, False, torch.empty(Cout, Cin, device=dev), Cout, Cin, R, ex)
+                e = rel(dw, dyd.t() @ a_ref); worst = max(worst, e); assert e < 1e-5, ("wgrad pro", R, Cin, Cout, split, e)
+    # strided gather (downsample.0: 1x1, stride 2)
+    Bn, Hi, Cin, Cout = 3, 8, 64, 128
+    xm = torch.randn(Bn, Hi, Hi, Cin, generator=g).to(dev); w = (0.1 * torch.randn(Cout, Cin, generator=g)).to(dev)
+    xs = xm[:, ::2, ::2].reshape(-1, Cin).contiguous()
+    R = xs.shape[0]
+    ex = ConvExtra(stride=2, Hi=Hi, Wi=Hi, Ho=Hi // 2, Wo=Hi // 2)
+    y = cgemm(xm.view(-1, Cin), w, False, True, torch.empty(R, Cout, device=dev), R, Cout, Cin, ex)
+    e = rel(y, xs.double() @ w.double().t()); assert e < 3e-6, ("gather fwd", e)
+    dy = torch.randn(R, Cout, generator=g).to(dev)
+    dw = cgemm(dy, xm.view(-1, Cin), True, False, torch.empty(Cout, Cin, device=dev), Cout, Cin, R, ex)
+    e = rel(dw, dy.double().t() @ xs.double()); assert e < 1e-5, ("gather wgrad", e)
+    # TT and odd shapes through the generic entry
+    a = torch.randn(96, 200, generator=g).to(dev); b = torch.randn(60, 96, generator=g).to(dev)
+    o = cgemm(a, b, True, True, torch.empty(200, 60, device=dev), 200, 60, 96)
+    e = rel(o, a.double().t() @ b.double().t()); assert e < 3e-6, ("TT", e)
+    print("check ok, worst rel err %.2e" % worst, flush=True)
+
+
+def timeit():
+    shapes = [("l1.conv1", 64, 64, 256, 64), ("l1.conv3", 64, 64, 64, 256), ("l2.conv1", 32, 32, 512, 128),
+              ("l2.conv3", 32, 32, 128, 512), ("l3.conv1", 16, 16, 1024, 256), ("l3.conv3", 16, 16, 256, 1024),
+              ("l4.conv1", 8, 8, 2048, 512), ("l4.conv3", 8, 8, 512, 2048)]
+    B = 32
+    print("%-9s %6s %5s %5s | fwd: new  +pro+epi  old  miopen (TF new) | dgrad: new +mask old miopen | wgrad: new +pro old miopen"
+          % ("layer", "R", "Cin", "Cout"), flush=True)
+    for name, H, W, Cin, Cout in shapes:
+        R = B * H * W
+        x = torch.randn(B, Cin, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+        w = (0.1 * torch.randn(Cout, Cin, 1, 1, device=dev)).contiguous(memory_format=torch.channels_last)
+        dy = torch.randn(B, Cout, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+        x2 = x.permute(0, 2, 3, 1).reshape(R, Cin); w2 = w.view(Cout, Cin); dy2 = dy.permute(0, 2, 3, 1).reshape(R, Cout)
+        y2 = torch.empty(R, Cout, device=dev); dx2 = torch.empty(R, Cin, device=dev); dw2 = torch.empty(Cout, Cin, device=dev)
+        sc = torch.rand(Cin, device=dev) + 0.5; sh = torch.randn(Cin, device=dev) * 0.1
+        ss = torch.stack([sc, sh], dim=1).contiguous()
+        mt = lib().scnattn_cgemm_row_tiles(R)
+        part = torch.empty(mt, 2, max(Cin, Cout), device=dev)
+        z = torch.randn(R, Cin, device=dev); v = torch.rand(Cin, device=dev) + 0.5
+        exf = ConvExtra(pro=1, epi=1, pro_ss=ss.data_ptr(), stat_partial=part.data_ptr())
+        exd = ConvExtra(epi=2, stat_partial=part.data_ptr(), ez=z.data_ptr(), emean=sh.data_ptr(), einvstd=v.data_ptr(),
+                        egamma=v.data_ptr(), ebeta=sh.data_ptr(), ldz=Cin)
+        exw = ConvExtra(pro=2, pro_ss=ss.data_ptr())
+        f0 = t_us(lambda: cgemm(x2, w2, False, True, y2, R, Cout, Cin))
+        f1 = t_us(lambda: cgemm(x2, w2, False, True, y2, R, Cout, Cin, exf))
+        SF.set_option("use_cgemm", 0)
+        f2 = t_us(lambda: SF.gemm(x2, w2, tb=True, out=y2))
+        g2 = t_us(lambda: SF.gemm(dy2, w2, out=dx2))
+        h2 = t_us(lambda: SF.gemm(dy2, x2, ta=True, out=dw2))
+        SF.set_option("use_cgemm", 1)
+        f3 = t_us(lambda: F.conv2d(x, w))
+        g0 = t_us(lambda: cgemm(dy2, w2, False, False, dx2, R, Cin, Cout))
+        g1 = t_us(lambda: cgemm(dy2, w2, False, False, dx2, R, Cin, Cout, exd))
+        g3 = t_us(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [True, False, False]))
+        h0 = t_us(lambda: cgemm(dy2, x2, True, False, dw2, Cout, Cin, R))
+        h1 = t_us(lambda: cgemm(dy2, x2, True, False, dw2, Cout, Cin, R, exw))
+        h3 = t_us(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False]))
+        fl = 2.0 * R * Cin * Cout
+        print("%-9s %6d %5d %5d | %6.1f %6.1f %6.1f %6.1f (%5.1f) | %6.1f %6.1f %6.1f %6.1f | %6.1f %6.1f %7.1f %6.1f"
+              % (name, R, Cin, Cout, f0, f1, f2, f3, fl / f0 / 1e6, g0, g1, g2, g3, h0, h1, h2, h3), flush=True)
+    print("decoder / square shapes: new vs old (TF)")
+    for (M, N, K, ta, tb) in [(4096, 4096, 4096, 0, 1), (4096, 4096, 4096, 0, 0), (4096, 4096, 4096, 1, 0), (1632, 10000, 512, 0, 1),
+                              (10000, 512, 1632, 1, 0), (1632, 512, 10000, 0, 0), (2048, 512, 2048, 0, 1), (1632, 2048, 512, 0, 0),
+                              (32, 2048, 1000, 0, 0), (32, 512, 2048, 0, 1), (512, 2048, 1632, 1, 0), (2048, 2048, 1632, 1, 0)]:
+        a = torch.randn((K, M) if ta else (M, K), device=dev); b = torch.randn((N, K) if tb else (K, N), device=dev)
+        o = torch.empty(M, N, device=dev)
+        t0 = t_us(lambda: cgemm(a, b, ta, tb, o, M, N, K))
+        SF.set_option("use_cgemm", 0)
+        t1 = t_us(lambda: SF.gemm(a, b, ta=bool(ta), tb=bool(tb), out=o))
+        SF.set_option("use_cgemm", 1)
+        t2 = t_us(lambda: torch.mm(a.t() if ta else a, b.t() if tb else b, out=o))
+        fl = 2.0 * M * N * K
+        print("M=%5d N=%5d K=%5d ta=%d tb=%d | new %7.1f us %6.1f TF | old %7.1f us %6.1f TF | torch.mm %7.1f us %6.1f TF"
+              % (M, N, K, ta, tb, t0, fl / t0 / 1e6, t1, fl / t1 / 1e6, t2, fl / t2 / 1e6), flush=True)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("check", "all"):
+        check()
+    if what in ("time", "all"):
+        timeit()
