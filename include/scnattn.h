@@ -246,7 +246,7 @@ int scnattn_bn_bwd(void* stream, int R, int C, const void* dy, const void* y, co
  *   pro_ss [Cin][2] = {scale, shift} (fwd, wgrad): the input operand is taken as relu(x * scale[c] + shift[c]) --
  *       the previous BatchNorm + ReLU folded to one fma per element (scale = gamma*invstd, shift = beta - mean*scale,
  *       written interleaved by scnattn_bn_finalize) -- so the normalised map is never written to or read from HBM;
- *   stat_partial [scnattn_cgemm_row_tiles(R)][2][Cout] (fwd): per 128-row tile and output channel, sum(y - s) and
+ *   stat_partial [scnattn_cgemm_row_tiles(R)][2][Cout] (fwd): per 64-row block and output channel, sum(y - s) and
  *       sum((y - s)^2) with s = stat_shift[c] (or 0): the statistics pass of the NEXT BatchNorm, fixed order;
  *   ez / emean / einvstd / egamma / ebeta (dgrad): the result is masked with the ReLU mask recomputed from the
  *       BatchNorm input z ([R][Cin], leading dimension ldz), g = dx * [fma((z-mean)*invstd, gamma, beta) > 0], and
@@ -261,6 +261,7 @@ typedef struct scnattn_conv_extra {
     const float* ez; const float* emean; const float* einvstd; const float* egamma; const float* ebeta; long ldz;
     int stride, Hi, Wi, Ho, Wo;
     int force_split;          /* > 0: force the split-K factor (tests, tuning) */
+    int force_mi;             /* 1 / 2: force the 64- / 128-row tile (tests, tuning) */
 } scnattn_conv_extra;
 /* C = alpha*op(A).op(B) + beta*C + bias, rows with rowmask == 0 written as 0: same contract as scnattn_sgemm_ws, on
  * the LDS-DMA pipelined kernel; needs 16-byte aligned operands (returns -1 otherwise; scnattn_sgemm_ws picks the
@@ -273,9 +274,11 @@ int scnattn_cgemm_row_tiles(int M);
 /* y [R][Cout] = f(x) . w^T, w [Cout][Cin] (a channels-last 1x1 conv weight); R = output rows */
 int scnattn_conv1x1_fwd(void* stream, int R, int Cin, int Cout, const float* x, const float* w, float* y,
                         const scnattn_conv_extra* ex, float* ws, long ws_floats);
-/* dx [R][Cin] = dy [R][Cout] . w (+ beta * dx: the residual branch's gradient is accumulated in place) */
-int scnattn_conv1x1_dgrad(void* stream, int R, int Cin, int Cout, const float* dy, const float* w, float beta,
-                          float* dx, const scnattn_conv_extra* ex, float* ws, long ws_floats);
+/* dx [R][Cin] = dy [R][Cout] . w (+ beta * dx: the residual branch's gradient is accumulated in place).
+ * w_transposed != 0: `w` is the weight already transposed to [Cin][Cout] (scnattn_transpose2d), which puts both
+ * operands on the k-contiguous LDS image -- worth it when Cin is large and Cout small (conv1 of a bottleneck). */
+int scnattn_conv1x1_dgrad(void* stream, int R, int Cin, int Cout, const float* dy, const float* w, int w_transposed,
+                          float beta, float* dx, const scnattn_conv_extra* ex, float* ws, long ws_floats);
 /* dw [Cout][Cin] = dy^T . f(x) */
 int scnattn_conv1x1_wgrad(void* stream, int R, int Cin, int Cout, const float* dy, const float* x, float* dw,
                           const scnattn_conv_extra* ex, float* ws, long ws_floats);
@@ -285,6 +288,14 @@ int scnattn_conv1x1_wgrad(void* stream, int R, int Cin, int Cout, const float* d
 int scnattn_bn_finalize(void* stream, long R, int C, int nchunk, const float* partial, const float* shift, float eps,
                         float momentum, float* mean, float* invstd, float* run_mean, float* run_var,
                         const float* gamma, const float* beta, float* ss_out);
+/* scnattn_bn_stats (fp32 maps) that also writes the folded {scale, shift} pairs [C][2] for a consumer's prologue */
+int scnattn_bn_stats_fold(void* stream, int R, int C, const void* x, float eps, float momentum, float* partial,
+                          float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma,
+                          const float* beta, float* ss_out);
+/* The element-wise half of the BatchNorm backward on an already masked g (written, with its column sums, by the
+ * dgrad mask epilogue): dz = gamma*invstd*(g - dbeta/R - xhat*dgamma/R) */
+int scnattn_bn_bwd_dx(void* stream, int R, int C, const float* g, const float* z, const float* mean, const float* invstd,
+                      const float* gamma, const float* dbeta, const float* dgamma, float* dz);
 /* dbeta[c] = sum_chunks partial[.][0][c], dgamma[c] = sum_chunks partial[.][1][c] (the mask epilogue's sums) */
 int scnattn_bn_bwd_finalize(void* stream, int C, int nchunk, const float* partial, float* dbeta, float* dgamma);
 

@@ -24,7 +24,7 @@ extern int g_profile;
 extern int g_fuse_attn;
 extern int g_chains;
 extern int g_attn_depth;
-extern int g_gemm_target, g_gemm_kmin, g_gemm_kmin_small, g_gemm_gate, g_use_cgemm, g_cgemm_target, g_cgemm_kmin;
+extern int g_gemm_target, g_gemm_kmin, g_gemm_kmin_small, g_gemm_gate, g_use_cgemm, g_cgemm_target, g_cgemm_kmin, g_cgemm_vec, g_cgemm_mi;
 int profile_collect(double* out);
 int seq_workspace(const scnattn_dims* d, const scnattn_pool* pool, size_t* saved_bytes, size_t* scratch_bytes);
 int seq_fwd(hipStream_t st, const scnattn_dims* d, const scnattn_params* w, const float* enc, const float* tags,
@@ -65,6 +65,8 @@ int scnattn_set_option(const char* name, int value) {
     if (name && std::strcmp(name, "gemm_kmin") == 0 && value >= 16) { g_gemm_kmin = value; return 0; }
     if (name && std::strcmp(name, "gemm_kmin_small") == 0 && value >= 16) { g_gemm_kmin_small = value; return 0; }
     if (name && std::strcmp(name, "use_cgemm") == 0) { g_use_cgemm = value != 0; return 0; }
+    if (name && std::strcmp(name, "cgemm_vec") == 0) { g_cgemm_vec = value != 0; return 0; }
+    if (name && std::strcmp(name, "cgemm_mi") == 0 && value >= 0 && value <= 2) { g_cgemm_mi = value; return 0; }
     if (name && std::strcmp(name, "cgemm_target") == 0 && value >= 1) { g_cgemm_target = value; return 0; }
     if (name && std::strcmp(name, "cgemm_kmin") == 0 && value >= 16) { g_cgemm_kmin = value; return 0; }
     if (name && std::strcmp(name, "profile") == 0) {
@@ -122,7 +124,7 @@ static ConvExtra to_extra(const scnattn_conv_extra* e) {
     x.stat_partial = e->stat_partial; x.stat_shift = e->stat_shift;
     x.ez = e->ez; x.emean = e->emean; x.einvstd = e->einvstd; x.egamma = e->egamma; x.ebeta = e->ebeta; x.ldz = e->ldz;
     x.stride = e->stride < 1 ? 1 : e->stride; x.Hi = e->Hi; x.Wi = e->Wi; x.Ho = e->Ho; x.Wo = e->Wo;
-    x.force_split = e->force_split;
+    x.force_split = e->force_split; x.force_mi = e->force_mi;
     return x;
 }
 
@@ -145,10 +147,13 @@ int scnattn_conv1x1_fwd(void* stream, int R, int Cin, int Cout, const float* x, 
                  ws, ws ? ws_floats : 0, ex ? &e : nullptr);
 }
 
-int scnattn_conv1x1_dgrad(void* stream, int R, int Cin, int Cout, const float* dy, const float* w, float beta,
-                          float* dx, const scnattn_conv_extra* ex, float* ws, long ws_floats) {
+int scnattn_conv1x1_dgrad(void* stream, int R, int Cin, int Cout, const float* dy, const float* w, int w_transposed,
+                          float beta, float* dx, const scnattn_conv_extra* ex, float* ws, long ws_floats) {
     const ConvExtra e = to_extra(ex);
     SCN_ARG(!ex || (ex->pro == 0 && ex->stride <= 1), "conv1x1_dgrad: no prologue / stride here");
+    if (w_transposed)   // w is [Cin][Cout]: dx = dy . (w^T)^T, both operands k-contiguous
+        return cgemm(ST(stream), false, true, R, Cin, Cout, 1.f, dy, Cout, w, Cout, beta, dx, Cin, nullptr, nullptr, 1, 0,
+                     0, 0, ws, ws ? ws_floats : 0, ex ? &e : nullptr);
     return cgemm(ST(stream), false, false, R, Cin, Cout, 1.f, dy, Cout, w, Cin, beta, dx, Cin, nullptr, nullptr, 1, 0, 0,
                  0, ws, ws ? ws_floats : 0, ex ? &e : nullptr);
 }
@@ -166,6 +171,17 @@ int scnattn_bn_finalize(void* stream, long R, int C, int nchunk, const float* pa
                         const float* gamma, const float* beta, float* ss_out) {
     return bn_finalize(ST(stream), R, C, nchunk, partial, shift, eps, momentum, mean, invstd, run_mean, run_var, gamma,
                        beta, ss_out);
+}
+
+int scnattn_bn_stats_fold(void* stream, int R, int C, const void* x, float eps, float momentum, float* partial,
+                          float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma,
+                          const float* beta, float* ss_out) {
+    return bn_stats(ST(stream), R, C, x, 0, eps, momentum, partial, mean, invstd, run_mean, run_var, gamma, beta, ss_out);
+}
+
+int scnattn_bn_bwd_dx(void* stream, int R, int C, const float* g, const float* z, const float* mean, const float* invstd,
+                      const float* gamma, const float* dbeta, const float* dgamma, float* dz) {
+    return bn_bwd_dx(ST(stream), R, C, g, z, mean, invstd, gamma, dbeta, dgamma, dz);
 }
 
 int scnattn_bn_bwd_finalize(void* stream, int C, int nchunk, const float* partial, float* dbeta, float* dgamma) {

@@ -121,7 +121,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_finalize_kernel(int R, int C, int nchunk, const T* __restrict__ x,
                                                           const float* __restrict__ partial, float eps, float momentum,
                                                           float* __restrict__ mean, float* __restrict__ invstd,
-                                                          float* __restrict__ run_mean, float* __restrict__ run_var) {
+                                                          float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ ss_out) {
     __shared__ float red[16][2][17];
     const int c = blockIdx.x * 16 + (threadIdx.x & 15), lane16 = threadIdx.x >> 4;
     float s1, s2;
@@ -134,6 +136,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(int R, int C, int nchu
     if (var < 0.f) var = 0.f;
     mean[c] = mu;
     invstd[c] = rsqrtf(var + eps);
+    if (ss_out) {      // folded {scale, shift} for a consumer that normalises on load (cgemm.hip prologues)
+        const float sc = gamma[c] * rsqrtf(var + eps);
+        ss_out[2 * c] = sc;
+        ss_out[2 * c + 1] = fmaf(-mu, sc, beta[c]);
+    }
     if (run_mean) run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mu;
     if (run_var) {
         const float unbiased = R > 1 ? var * ((float)R / (float)(R - 1)) : var;
@@ -144,9 +151,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(int R, int C, int nchu
 // Same as bn_finalize_kernel for partials written by a GEMM statistics epilogue (shift vector instead of x[0][c]),
 // plus the folded scale/shift a consumer's prologue applies.
 __global__ __launch_bounds__(256) void bn_finalize_shift_kernel(long R, int C, int nchunk, const float* __restrict__ partial,
-                                                                const float* __restrict__ shift, float eps, float momentum,
+                                                                const float* shift, float eps, float momentum,
                                                                 float* __restrict__ mean, float* __restrict__ invstd,
-                                                                float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                                float* run_mean, float* __restrict__ run_var,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 float* __restrict__ ss_out) {
     __shared__ float red[16][2][17];
@@ -373,23 +380,37 @@ int bn_bwd_finalize(hipStream_t st, int C, int nchunk, const float* partial, flo
 
 template <typename T>
 static int bn_stats_t(hipStream_t st, int R, int C, const T* x, float eps, float momentum, float* partial, float* mean,
-                      float* invstd, float* run_mean, float* run_var) {
+                      float* invstd, float* run_mean, float* run_var, const float* gamma, const float* beta, float* ss_out) {
     int rpc;
     const int nchunk = pick_chunks(R, C, &rpc);
     hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(cdiv(C, 64), nchunk), dim3(256), 0, st, R, C, rpc, x, partial);
     SCN_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_finalize_kernel<T>, dim3(cdiv(C, 16)), dim3(256), 0, st, R, C, nchunk, x, partial, eps,
-                       momentum, mean, invstd, run_mean, run_var);
+                       momentum, mean, invstd, run_mean, run_var, gamma, beta, ss_out);
     SCN_LAUNCH_CHECK();
     return 0;
 }
 
 int bn_stats(hipStream_t st, int R, int C, const void* x, int bf16, float eps, float momentum, float* partial,
-             float* mean, float* invstd, float* run_mean, float* run_var) {
+             float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma, const float* beta,
+             float* ss_out) {
     SCN_ARG(R > 0 && C > 0 && C % 4 == 0 && x && partial && mean && invstd, "bn_stats: bad argument");
     SCN_ARG((reinterpret_cast<uintptr_t>(x) & (bf16 ? 7u : 15u)) == 0, "bn_stats: x is not vector aligned");
-    if (bf16) return bn_stats_t<__bf16>(st, R, C, (const __bf16*)x, eps, momentum, partial, mean, invstd, run_mean, run_var);
-    return bn_stats_t<float>(st, R, C, (const float*)x, eps, momentum, partial, mean, invstd, run_mean, run_var);
+    SCN_ARG(!ss_out || (gamma && beta), "bn_stats: folded scale/shift need gamma and beta");
+    if (bf16) return bn_stats_t<__bf16>(st, R, C, (const __bf16*)x, eps, momentum, partial, mean, invstd, run_mean, run_var, gamma, beta, ss_out);
+    return bn_stats_t<float>(st, R, C, (const float*)x, eps, momentum, partial, mean, invstd, run_mean, run_var, gamma, beta, ss_out);
+}
+
+// dz = gamma*invstd*(g - dbeta/R - xhat*dgamma/R) from an ALREADY masked g (the dgrad mask epilogue of cgemm.hip wrote it
+// and its two column sums): the element-wise half of the BatchNorm backward alone
+int bn_bwd_dx(hipStream_t st, int R, int C, const float* g, const float* z, const float* mean, const float* invstd,
+              const float* gamma, const float* dbeta, const float* dgamma, float* dz) {
+    SCN_ARG(R > 0 && C > 0 && C % 4 == 0 && g && z && mean && invstd && gamma && dbeta && dgamma && dz, "bn_bwd_dx: bad argument");
+    const long n4 = (long)R * C / 4;
+    hipLaunchKernelGGL((bn_bwd_dx_kernel<float, false, true, false>), dim3(ew_blocks(n4)), dim3(256), 0, st, n4, R, C, g,
+                       (const float*)nullptr, z, mean, invstd, gamma, (const float*)nullptr, dbeta, dgamma, dz, (float*)nullptr);
+    SCN_LAUNCH_CHECK();
+    return 0;
 }
 
 template <typename T>

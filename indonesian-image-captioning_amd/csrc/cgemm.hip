@@ -7,7 +7,8 @@
 // of models/attention.py:35, attention_scn.py:154, scn_cell.py:73-86 that csrc/sgemm.hip served in round 1.
 //
 // Structure (MI355X_MICROARCH / cdna_hip_programming "Pipelining across barriers"):
-//   * 128x128x16 block tile, 4 waves as 2x2, each wave 2x2 MFMA 32x32 tiles;
+//   * 128x128x16 block tile, 4 waves as 2x2, each wave 2x2 MFMA 32x32 tiles (MI = 2); a 64x128x16 variant (MI = 1,
+//     each wave 1x2 tiles) for products whose 128-row tile grid cannot fill 256 CUs but whose 64-row grid can;
 //   * operands go global -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, 1 KiB per wave-instruction, hardware
 //     range checking: rows / k beyond the matrix land as zeros), 3-stage ring, ONE raw s_barrier per k-step and a
 //     counted `s_waitcnt vmcnt(N)` that leaves the next tile's loads in flight across it;
@@ -24,10 +25,13 @@
 //     BatchNorm + ReLU folded to one fma, per input channel) -- the normalised map is never written to HBM;
 //     scale/shift of the current k-step travel through the LDS ring with the tile;
 //   * optional per-column prologue on a MC B operand (wgrad: B = relu(bn(z)) with the channel on the column);
-//   * optional statistics epilogue: per (row-tile, column) sums of (y - s) and (y - s)^2 for the NEXT BatchNorm
-//     (s = a per-channel shift for conditioning, e.g. the running mean), fixed order, no atomics;
-//   * optional mask/statistics epilogue for dgrad: g = acc * [relu-mask recomputed from z], column sums of g and
-//     g*xhat (the BatchNorm backward reductions), g stored;
+//   * optional statistics epilogue: per (64-row block, column) sums of (y - s) and (y - s)^2 for the NEXT BatchNorm
+//     (s = a per-channel shift for conditioning, e.g. the running mean), fixed order, no atomics, taken straight from
+//     the accumulators before the stores are issued;
+//   * optional mask/statistics pass for dgrad (cstats_kernel<2>, also the split-K reducer): g = dx * [relu-mask
+//     recomputed from z], column sums of g and g*xhat (the BatchNorm backward reductions), g stored in place;
+//   * C rows (and split-K slab rows) leave through a wave-private LDS transpose as 16-byte range-checked buffer stores
+//     (16 store instructions per wave instead of 64);
 //   * split-K into slabs reduced by a second launch in slab order (deterministic), for shapes whose tile grid alone
 //     cannot fill 256 CUs.
 #include "common.h"
@@ -37,10 +41,11 @@ namespace scn {
 
 namespace {
 
-constexpr int TM = 128, TN = 128, TK = 16, NSTAGE = 3;
-constexpr int TILE_F = TM * TK;                 // floats per operand tile (8 KiB)
-constexpr int AUX_F = 4 * 64;                   // per-wave [scale 16 | shift 16 | pad 32] of the current k-step (1 KiB)
+constexpr int TN = 128, TK = 16, NSTAGE = 3;
+constexpr int TILE_F = 128 * TK;                // floats reserved per operand tile (8 KiB)
+constexpr int AUX_F = 4 * 64;                   // per-wave {scale, shift} pairs of the current k-step (1 KiB)
 constexpr int STAGE_F = 2 * TILE_F + AUX_F;     // 17 KiB per stage -> 51 KiB per workgroup, 3 workgroups per CU
+constexpr int SROWS = 64;                       // rows per statistics partial
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
@@ -56,8 +61,8 @@ struct CArgs {
     // conv extras
     int gHi, gWi, gHo, gWo, gs;   // row gather (strided 1x1 convolution); gs == 0: none
     const float* pro_ss;          // interleaved {scale, shift} per channel: PRO 1 per k (A), PRO 2 per n (B)
-    float* stat_partial; const float* stat_shift;       // EPI 1: [mt][2][N]
-    const float* ez; const float* emean; const float* einvstd; const float* egamma; const float* ebeta;  // EPI 2
+    float* stat_partial; const float* stat_shift;       // [cdiv(M, 64)][2][N]
+    const float* ez; const float* emean; const float* einvstd; const float* egamma; const float* ebeta;  // mask pass
     long ldz;
 };
 
@@ -76,22 +81,30 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, float* lds_wave
 __device__ __forceinline__ void dma4(__amdgpu_buffer_rsrc_t rs, float* lds_wave_base, unsigned voff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)lds_wave_base, 4, voff, 0, 0, 0);
 }
+__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned byte_off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, 0);
+}
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else static_assert(N < 0, "unsupported count");
 }
 
+// MI: 32-row MFMA tiles per wave along m (block tile = 64*MI x 128).
 // A_MC / B_MC: operand stored with its m / n dimension contiguous ([K][M] / [K][N]); otherwise k contiguous.
 // PRO: 0 none, 1 relu(a*scale[k]+shift[k]) on a KC A operand, 2 relu(b*scale[n]+shift[n]) on a MC B operand.
-// EPI: 0 plain (alpha, beta, bias, rowmask), 1 plain store + column statistics, 2 relu-mask from z + BN-backward sums.
-// AGATHER: rows of a KC A operand (PRO 0/1) or k-rows of a MC B operand are gathered (strided 1x1 convolution).
-template <bool A_MC, bool B_MC, int PRO, int EPI, bool GATHER>
+// EPI: 0 plain (alpha, beta, bias, rowmask), 1 plain store + column statistics.
+// GATHER: rows of a KC A operand or k-rows of a MC B operand are gathered (strided 1x1 convolution).
+// VEC: the output takes 16-byte row stores.
+template <int MI, bool A_MC, bool B_MC, int PRO, int EPI, bool GATHER, bool VEC>
 __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
     __shared__ __attribute__((aligned(16))) float lds[NSTAGE * STAGE_F];
-    constexpr int LPT = 4 + (PRO == 1 ? 1 : 0);       // LDS-DMA instructions per wave per tile
+    constexpr int TM = 64 * MI;
+    constexpr int ACH = MI;                            // A chunks (1 KiB LDS-DMA pieces) per wave per tile
+    constexpr int LPT = ACH + 2 + (PRO == 1 ? 1 : 0);  // LDS-DMA instructions per wave per tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -121,25 +134,33 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
     const __amdgpu_buffer_rsrc_t brs = make_rsrc(B, (unsigned)(b_elems * 4));
     const __amdgpu_buffer_rsrc_t srs = make_rsrc(g.pro_ss, PRO == 1 ? (unsigned)g.K * 8u : 0u);
 
-    // ---- per-lane source offsets of the two chunks this wave stages per operand ------------------------------
+    // ---- per-lane source offsets of the chunks this wave stages per operand ---------------------------------
     // KC: chunk = 16 rows x 64 B; lane -> row chunk*16 + lane/4, LDS granule lane&3 <- source granule (lane&3)^((row>>2)&3)
-    // MC: chunk = 2 k-rows x 512 B; lane -> k-row chunk*2 + lane/32, columns 4*(lane&31)
-    unsigned a_off[2], b_off[2];     // byte offsets at k = kbeg (KC: + k*4; MC: + k*ld*4 per step)
-    bool a_ok[2], b_ok[2];
+    // MC: chunk = 2 k-rows x 512 B (256 B when the tile is 64 wide: A with MI = 1); lane -> k-row, 4 columns
+    unsigned a_off[ACH], b_off[2];   // byte offsets at k = kbeg (KC: + k*4; MC: + k*ld*4 per step)
+    bool a_ok[ACH], b_ok[2];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int chunk = wave * 2 + c;
+    for (int c = 0; c < ACH; ++c) {
+        const int chunk = wave * ACH + c;
         if (!A_MC) {
             const int row = chunk * 16 + (lane >> 2), gsrc = (lane & 3) ^ ((row >> 2) & 3);
             const int grow = m0 + row;
             a_ok[c] = grow < g.M;
             const long src = (GATHER ? gather_row(g, a_ok[c] ? grow : 0) : (long)grow) * g.lda + gsrc * 4;
             a_off[c] = (unsigned)(src * 4);
-        } else {
+        } else if (MI == 2) {
             const int col = m0 + 4 * (lane & 31);
             a_ok[c] = col < g.M;
             a_off[c] = (unsigned)(((long)(chunk * 2 + (lane >> 5)) * g.lda + col) * 4);
+        } else {        // 64-wide [k][64] image: a chunk = 4 k-rows x 256 B
+            const int col = m0 + 4 * (lane & 15);
+            a_ok[c] = col < g.M;
+            a_off[c] = (unsigned)(((long)(chunk * 4 + (lane >> 4)) * g.lda + col) * 4);
         }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int chunk = wave * 2 + c;
         if (!B_MC) {
             const int row = chunk * 16 + (lane >> 2), gsrc = (lane & 3) ^ ((row >> 2) & 3);
             const int grow = n0 + row;
@@ -157,17 +178,22 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
         float* sb = sa + TILE_F;
         const int k0 = kbeg + kt * TK;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int chunk = wave * 2 + c;
-            unsigned va, vb;
+        for (int c = 0; c < ACH; ++c) {
+            const int chunk = wave * ACH + c;
+            unsigned va;
             if (!A_MC) {
                 const int kk = k0 + 4 * ((lane & 3) ^ (((chunk * 16 + (lane >> 2)) >> 2) & 3));
                 va = (a_ok[c] && kk < Kend) ? a_off[c] + (unsigned)k0 * 4u : OOB_OFF;
             } else {
-                const int kr = k0 + chunk * 2 + (lane >> 5);
+                const int kr = k0 + (MI == 2 ? chunk * 2 + (lane >> 5) : chunk * 4 + (lane >> 4));
                 va = (a_ok[c] && kr < Kend) ? a_off[c] + (unsigned)((long)k0 * g.lda * 4) : OOB_OFF;
             }
             dma16(ars, sa + chunk * 256, va);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int chunk = wave * 2 + c;
+            unsigned vb;
             if (!B_MC) {
                 const int kk = k0 + 4 * ((lane & 3) ^ (((chunk * 16 + (lane >> 2)) >> 2) & 3));
                 vb = (b_ok[c] && kk < Kend) ? b_off[c] + (unsigned)k0 * 4u : OOB_OFF;
@@ -189,9 +215,9 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -209,9 +235,33 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
         for (int j = 0; j < 2; ++j) { asm volatile("" : "+v"(bsc[j])); asm volatile("" : "+v"(bsh[j])); }
     }
 
+    // PRO 1: normalise-on-load as an in-place pass over the part of the A tile THIS wave staged, between the wait that
+    // retires its DMA and the barrier that publishes the tile: every element once (not once per consuming wave) and off
+    // the MFMA dependency chain.  Lane -> one 16-byte granule = 4 consecutive k of one row; its {scale, shift} pairs
+    // sit in this wave's copy of the k-step's table.
+    auto prologue_in_lds = [&](int stg) {
+        float* sa = lds + stg * STAGE_F;
+        const float* sx = sa + 2 * TILE_F + wave * 64;
+#pragma unroll
+        for (int c = 0; c < ACH; ++c) {
+            const int chunk = wave * ACH + c;
+            const int row = chunk * 16 + (lane >> 2), gsrc = (lane & 3) ^ ((row >> 2) & 3);     // source granule = k/4
+            float* p = sa + chunk * 256 + lane * 4;
+            f32x4 v = *reinterpret_cast<f32x4*>(p);
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(sx + 8 * gsrc), t1 = *reinterpret_cast<const f32x4*>(sx + 8 * gsrc + 4);
+            v[0] = fmaxf(fmaf(v[0], t0[0], t0[1]), 0.f);
+            v[1] = fmaxf(fmaf(v[1], t0[2], t0[3]), 0.f);
+            v[2] = fmaxf(fmaf(v[2], t1[0], t1[1]), 0.f);
+            v[3] = fmaxf(fmaf(v[3], t1[2], t1[3]), 0.f);
+            *reinterpret_cast<f32x4*>(p) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+
     if (nk > 0) issue(0, 0);
     if (nk > 1) issue(1, 1);
     if (nk > 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+    if (PRO == 1 && nk > 0) prologue_in_lds(0);
     __builtin_amdgcn_s_barrier();
 
     int stage = 0;
@@ -222,19 +272,19 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
         }
         const float* sa = lds + stage * STAGE_F;
         const float* sb = sa + TILE_F;
-        float a[2][8], b[2][8];
+        float a[MI][8], b[2][8];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MI; ++i) {
             if (!A_MC) {
-                const int row = wm * 64 + i * 32 + l31, sw = (row >> 2) & 3;
+                const int row = wm * 32 * MI + i * 32 + l31, sw = (row >> 2) & 3;
                 const f32x4 v0 = *reinterpret_cast<const f32x4*>(sa + row * 16 + (((2 * hh) ^ sw) << 2));
                 const f32x4 v1 = *reinterpret_cast<const f32x4*>(sa + row * 16 + (((2 * hh + 1) ^ sw) << 2));
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { a[i][q] = v0[q]; a[i][4 + q] = v1[q]; }
             } else {
-                const int col = wm * 64 + i * 32 + l31;
+                const int col = wm * 32 * MI + i * 32 + l31;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) a[i][q] = sa[(8 * hh + q) * 128 + col];
+                for (int q = 0; q < 8; ++q) a[i][q] = sa[(8 * hh + q) * TM + col];
             }
         }
 #pragma unroll
@@ -251,17 +301,6 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
                 for (int q = 0; q < 8; ++q) b[j][q] = sb[(8 * hh + q) * 128 + col];
             }
         }
-        if (PRO == 1) {
-            const float* sx = sa + 2 * TILE_F + wave * 64 + 16 * hh;     // {scale, shift} of k = 8h .. 8h+7
-            f32x4 t[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) t[q] = *reinterpret_cast<const f32x4*>(sx + 4 * q);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    a[i][q] = fmaxf(fmaf(a[i][q], t[q >> 1][(q & 1) * 2], t[q >> 1][(q & 1) * 2 + 1]), 0.f);
-        }
         if (PRO == 2) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -271,40 +310,178 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
 #pragma unroll
         for (int q = 0; q < 8; ++q)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
         // the next tile must have landed (this wave's part) before the barrier that publishes it to the others;
         // the tile after it stays in flight across the barrier
         if (kt + 2 < nk) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+        if (PRO == 1 && kt + 1 < nk) {
+            int s1 = stage + 1; if (s1 >= NSTAGE) s1 -= NSTAGE;
+            prologue_in_lds(s1);
+        }
         __builtin_amdgcn_s_barrier();
         if (++stage == NSTAGE) stage = 0;
     }
 
     // ================================== epilogues =====================================================
-    if (g.S > 1) {   // split-K: raw alpha-scaled partial tile; creduce_kernel applies the epilogue
-        float* W = g.ws + ((long)blockIdx.y * g.M) * g.N;
+    // The ring is dead by now (every wave passed the last barrier after its last fragment read).  Nothing waits on the
+    // stores: a workgroup's slot is free as soon as they are issued -- which is why the statistics come BEFORE them.
+    // An opaque zero that the offsets depend on keeps hipcc from computing the ~40 loop-invariant row offsets before
+    // the k-loop and spilling them around the MFMA chain.
+    unsigned opq = 0;
+    asm volatile("" : "+v"(opq));
+    float* const lw = lds + wave * 2048;           // [32 rows][64 cols]; 256-byte rows are conflict-free both ways
+    float* const colsum = lds + 4 * 2048;          // [wm][2][TN] (MI = 1 only), behind the four transpose regions
+    const int rl = lane >> 4, c4 = (lane & 15) * 4;
+    const int ncol = n0 + wn * 64 + c4;
+    const bool cok = ncol < g.N;
+    const long c_ld = g.S > 1 ? (long)g.N : g.ldc;
+    float* const c_base = g.S > 1 ? g.ws + ((long)blockIdx.y * g.M) * g.N : C;
+    const __amdgpu_buffer_rsrc_t ors = make_rsrc(c_base, VEC ? (unsigned)(((long)(g.M - 1) * c_ld + g.N) * 4) : 0u);
+    auto row_off = [&](int m) -> unsigned { return (m < g.M && cok) ? (unsigned)(((long)m * c_ld + ncol) * 4) + opq : OOB_OFF; };
+    // one 32-row block of this wave from the accumulators into the transpose region
+    auto dump_half = [&](int i, float add0, float add1) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int n = n0 + wn * 64 + j * 32 + l31;
+            for (int r = 0; r < 16; ++r)
+                lw[mfma32_row(r, lane) * 64 + j * 32 + l31] = g.alpha * acc[i][j][r] + (j ? add1 : add0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // same wave wrote it: only the LDS counter drains
+    };
+    const int mw0 = m0 + wm * 32 * MI;             // first row of this wave
+
+    if (g.S > 1) {   // split-K: raw alpha-scaled partial tile; the reduce kernels apply the epilogue
+        if constexpr (VEC) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * 64 + i * 32 + mfma32_row(r, lane);
-                    if (n < g.N && m < g.M) W[(long)m * g.N + n] = g.alpha * acc[i][j][r];
+            for (int i = 0; i < MI; ++i) {
+                dump_half(i, 0.f, 0.f);
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int row = it * 4 + rl;
+                    buf_store4(ors, row_off(mw0 + i * 32 + row), *reinterpret_cast<const f32x4*>(lw + row * 64 + c4));
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // reads done before the next block overwrites
             }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int n = n0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = mw0 + i * 32 + mfma32_row(r, lane);
+                        if (n < g.N && m < g.M) c_base[(long)m * g.N + n] = g.alpha * acc[i][j][r];
+                    }
+                }
+        }
         return;
     }
 
-    if (EPI == 0) {
+    if constexpr (VEC && EPI == 0) {
+        const bool use_c = g.beta != 0.f, use_m = g.rowmask != nullptr;
+        const __amdgpu_buffer_rsrc_t cr = make_rsrc(C, use_c ? (unsigned)(((long)(g.M - 1) * g.ldc + g.N) * 4) : 0u);
+        const __amdgpu_buffer_rsrc_t mr = make_rsrc(g.rowmask, use_m ? (unsigned)g.M * 4u : 0u);
+        float bv[2] = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + l31;
+            if (g.bias && n < g.N) bv[j] = g.bias[n];
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            f32x4 cv[8];
+            float mk[8];
+            if (use_c) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) cv[it] = buf_load4(cr, row_off(mw0 + i * 32 + it * 4 + rl));
+            }
+            if (use_m) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int m = mw0 + i * 32 + it * 4 + rl;
+                    mk[it] = buf_load(mr, m < g.M ? (unsigned)m * 4u + opq : OOB_OFF);
+                }
+            }
+            dump_half(i, bv[0], bv[1]);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 4 + rl;
+                f32x4 v = *reinterpret_cast<const f32x4*>(lw + row * 64 + c4);
+                if (use_c) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = fmaf(g.beta, cv[it][q], v[q]);
+                }
+                if (use_m && mk[it] == 0.f) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                buf_store4(ors, row_off(mw0 + i * 32 + row), v);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        return;
+    }
+
+    if constexpr (VEC && EPI == 1) {
+        // statistics first, straight from the accumulators (lane = column, registers = rows): one partial row per 64
+        // rows.  MI = 2: a wave owns 64 rows of its columns outright -> no exchange at all; MI = 1: the two row halves
+        // (wm) of the 64-row tile meet in LDS.
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + l31;
+            const float sft = (g.stat_shift && n < g.N) ? g.stat_shift[n] : 0.f;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mw0 + i * 32 + mfma32_row(r, lane);
+                    const float d = (m < g.M) ? g.alpha * acc[i][j][r] - sft : 0.f;
+                    s1 += d;
+                    s2 = fmaf(d, d, s2);
+                }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (MI == 2) {
+                if (lane < 32 && n < g.N && mw0 < g.M) {
+                    float* p = g.stat_partial + ((long)(tm * 2 + wm) * 2) * g.N + n;
+                    p[0] = s1;
+                    p[g.N] = s2;
+                }
+            } else if (lane < 32) {
+                colsum[(wm * 2 + 0) * TN + wn * 64 + j * 32 + l31] = s1;
+                colsum[(wm * 2 + 1) * TN + wn * 64 + j * 32 + l31] = s2;
+            }
+        }
+        if (MI == 1) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (tid < TN && n0 + tid < g.N) {
+                float* p = g.stat_partial + ((long)tm * 2) * g.N + n0 + tid;
+                p[0] = colsum[0 * TN + tid] + colsum[2 * TN + tid];
+                p[g.N] = colsum[1 * TN + tid] + colsum[3 * TN + tid];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            dump_half(i, 0.f, 0.f);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 4 + rl;
+                buf_store4(ors, row_off(mw0 + i * 32 + row), *reinterpret_cast<const f32x4*>(lw + row * 64 + c4));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        return;
+    }
+
+    // ---- scalar epilogue for outputs that cannot take 16-byte row stores (odd N / ldc): EPI 0 only ------------------
+    if constexpr (!VEC && EPI == 0) {
         const bool use_c = g.beta != 0.f, use_m = g.rowmask != nullptr;
         const __amdgpu_buffer_rsrc_t cr = make_rsrc(C, use_c ? (unsigned)(((long)(g.M - 1) * g.ldc + g.N) * 4) : 0u);
         const __amdgpu_buffer_rsrc_t mr = make_rsrc(g.rowmask, use_m ? (unsigned)g.M * 4u : 0u);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int n = n0 + wn * 64 + j * 32 + l31;
@@ -313,7 +490,7 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
                 if (use_c) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int m = m0 + wm * 64 + i * 32 + mfma32_row(r, lane);
+                        const int m = mw0 + i * 32 + mfma32_row(r, lane);
                         cv[r] = buf_load(cr, (nok && m < g.M) ? (unsigned)(((long)m * g.ldc + n) * 4) : OOB_OFF);
                     }
 #pragma unroll
@@ -322,7 +499,7 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
                 if (use_m) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int m = m0 + wm * 64 + i * 32 + mfma32_row(r, lane);
+                        const int m = mw0 + i * 32 + mfma32_row(r, lane);
                         mk[r] = buf_load(mr, m < g.M ? (unsigned)m * 4u : OOB_OFF);
                     }
 #pragma unroll
@@ -332,153 +509,127 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
                 if (g.bias && nok) bv = g.bias[n];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * 64 + i * 32 + mfma32_row(r, lane);
+                    const int m = mw0 + i * 32 + mfma32_row(r, lane);
                     float v = g.alpha * acc[i][j][r] + bv;
                     if (use_c) v += g.beta * cv[r];
                     if (use_m && mk[r] == 0.f) v = 0.f;
                     if (nok && m < g.M) C[(long)m * g.ldc + n] = v;
                 }
             }
-        return;
-    }
-
-    // EPI 1 / 2 share the column reduction: lanes l and l+32 hold the same column, the two row-halves (wm) meet in LDS
-    // (the ring is dead by now: every wave passed the last barrier after its last fragment read)
-    float* colsum = lds;                         // [wm][2][TN]
-    if (EPI == 1) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 64 + j * 32 + l31;
-            const bool nok = n < g.N;
-            const float sft = (g.stat_shift && nok) ? g.stat_shift[n] : 0.f;
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * 64 + i * 32 + mfma32_row(r, lane);
-                    const float v = g.alpha * acc[i][j][r];
-                    if (nok && m < g.M) {
-                        C[(long)m * g.ldc + n] = v;
-                        const float d = v - sft;
-                        s1 += d;
-                        s2 = fmaf(d, d, s2);
-                    }
-                }
-            s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            if (lane < 32) {
-                colsum[(wm * 2 + 0) * TN + wn * 64 + j * 32 + l31] = s1;
-                colsum[(wm * 2 + 1) * TN + wn * 64 + j * 32 + l31] = s2;
-            }
-        }
-    } else {   // EPI 2: g = acc * [fma((z-mean)*invstd, gamma, beta) > 0]; sums of g and g*xhat; store g
-        const __amdgpu_buffer_rsrc_t zr = make_rsrc(g.ez, (unsigned)(((long)(g.M - 1) * g.ldz + g.N) * 4));
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 64 + j * 32 + l31;
-            const bool nok = n < g.N;
-            float mu = 0.f, is = 0.f, ga = 0.f, be = 0.f;
-            if (nok) { mu = g.emean[n]; is = g.einvstd[n]; ga = g.egamma[n]; be = g.ebeta[n]; }
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                float zv[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * 64 + i * 32 + mfma32_row(r, lane);
-                    zv[r] = buf_load(zr, (nok && m < g.M) ? (unsigned)(((long)m * g.ldz + n) * 4) : OOB_OFF);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(zv[r]));
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * 64 + i * 32 + mfma32_row(r, lane);
-                    const float xh = (zv[r] - mu) * is;
-                    float v = g.alpha * acc[i][j][r];
-                    if (!(fmaf(xh, ga, be) > 0.f)) v = 0.f;
-                    if (nok && m < g.M) {
-                        C[(long)m * g.ldc + n] = v;
-                        s1 += v;
-                        s2 = fmaf(v, xh, s2);
-                    }
-                }
-            }
-            s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            if (lane < 32) {
-                colsum[(wm * 2 + 0) * TN + wn * 64 + j * 32 + l31] = s1;
-                colsum[(wm * 2 + 1) * TN + wn * 64 + j * 32 + l31] = s2;
-            }
-        }
-    }
-    __syncthreads();
-    if (tid < TN && n0 + tid < g.N) {
-        float* p = g.stat_partial + ((long)tm * 2) * g.N + n0 + tid;
-        p[0] = colsum[0 * TN + tid] + colsum[2 * TN + tid];
-        p[g.N] = colsum[1 * TN + tid] + colsum[3 * TN + tid];
     }
 }
 
-// Sum split-K slabs in slab order and apply the epilogue.  Without statistics: element-wise (grid.x blocks of 256).
+// Sum split-K slabs in slab order and apply the plain epilogue, 4 columns per thread when the output allows it.
+template <bool V4>
 __global__ __launch_bounds__(256) void creduce_kernel(CArgs g) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)g.M * g.N) return;
-    const int m = (int)(i / g.N), n = (int)(i - (long)m * g.N);
+    const long mn = (long)g.M * g.N;
     const int zb = blockIdx.y;
-    const float* W = g.ws + ((long)zb * g.S) * g.M * g.N;
-    float v = slab_sum(W, i, g.S, (long)g.M * g.N);
-    float* cp = g.C + (long)zb * g.sC + (long)m * g.ldc + n;
-    if (g.bias) v += g.bias[n];
-    if (g.beta != 0.f) v += g.beta * (*cp);
-    if (g.rowmask && g.rowmask[m] == 0.f) v = 0.f;
-    *cp = v;
+    const float* W = g.ws + ((long)zb * g.S) * mn;
+    if (V4) {
+        const long i4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+        if (i4 >= mn) return;
+        const int m = (int)(i4 / g.N), n = (int)(i4 - (long)m * g.N);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int s0 = 0; s0 < g.S; s0 += 8) {       // 8 loads in flight per round, fixed order
+            f32x4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const f32x4*>(W + (long)min(s0 + u, g.S - 1) * mn + i4);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (s0 + u < g.S) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] += t[u][q];
+                }
+        }
+        float* cp = g.C + (long)zb * g.sC + (long)m * g.ldc + n;
+        if (g.bias) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] += g.bias[n + q];
+        }
+        if (g.beta != 0.f) {
+            const f32x4 c = *reinterpret_cast<const f32x4*>(cp);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = fmaf(g.beta, c[q], v[q]);
+        }
+        if (g.rowmask && g.rowmask[m] == 0.f) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(cp) = v;
+    } else {
+        const long i = (long)blockIdx.x * 256 + threadIdx.x;
+        if (i >= mn) return;
+        const int m = (int)(i / g.N), n = (int)(i - (long)m * g.N);
+        float v = 0.f;
+        for (int s0 = 0; s0 < g.S; s0 += 16) v += slab_sum(W + (long)s0 * mn, i, min(16, g.S - s0), mn);
+        float* cp = g.C + (long)zb * g.sC + (long)m * g.ldc + n;
+        if (g.bias) v += g.bias[n];
+        if (g.beta != 0.f) v += g.beta * (*cp);
+        if (g.rowmask && g.rowmask[m] == 0.f) v = 0.f;
+        *cp = v;
+    }
 }
 
-// Split-K reduce with the statistics epilogues (EPI 1 / 2): a workgroup owns 128 rows x 64 columns; thread (rl, cl)
-// walks rows rl, rl+16, ... of 4 columns; partial[row-tile][2][N] exactly as the un-split kernel writes it.
-template <int EPI>
-__global__ __launch_bounds__(256) void creduce_stats_kernel(CArgs g) {
+// Statistics passes over a product, also the split-K reducer for them.  A workgroup owns 64 rows x 64 columns; thread
+// (rl, cl) walks rows rl, rl+16, rl+32, rl+48 of 4 columns with all its loads in flight; partial[64-row block][2][N].
+//   MODE 1: y = sum of S slabs -> C ; sums of (y - s), (y - s)^2.
+//   MODE 2: g = (sum of S slabs, or C itself when S == 0) * [fma((z-mean)*invstd, gamma, beta) > 0] -> C ; sums of g,
+//           g*xhat -- the ReLU mask and the two reductions of a BatchNorm backward folded into the dgrad that feeds it.
+template <int MODE>
+__global__ __launch_bounds__(256) void cstats_kernel(CArgs g) {
     __shared__ float red[16][2][64 + 1];
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.x * 64 + cl * 4;
-    const int r0 = blockIdx.y * TM, r1 = min(g.M, r0 + TM);
+    const int r0 = blockIdx.y * SROWS;
     float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     if (c < g.N) {
         f32x4 sft = {0.f, 0.f, 0.f, 0.f}, mu = sft, is = sft, ga = sft, be = sft;
-        if (EPI == 1 && g.stat_shift) sft = *reinterpret_cast<const f32x4*>(g.stat_shift + c);
-        if (EPI == 2) {
+        if (MODE == 1 && g.stat_shift) sft = *reinterpret_cast<const f32x4*>(g.stat_shift + c);
+        if (MODE == 2) {
             mu = *reinterpret_cast<const f32x4*>(g.emean + c);
             is = *reinterpret_cast<const f32x4*>(g.einvstd + c);
             ga = *reinterpret_cast<const f32x4*>(g.egamma + c);
             be = *reinterpret_cast<const f32x4*>(g.ebeta + c);
         }
-        for (int r = r0 + rl; r < r1; r += 16) {
-            const long idx = (long)r * g.N + c;
-            f32x4 v = *reinterpret_cast<const f32x4*>(g.ws + idx);
-            for (int s = 1; s < g.S; ++s) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(g.ws + (long)s * g.M * g.N + idx);
+        const long mn = (long)g.M * g.N;
+        f32x4 v[4], zz[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] += w[k];
+        for (int u = 0; u < 4; ++u) {
+            const int r = min(r0 + rl + 16 * u, g.M - 1);
+            v[u] = g.S > 0 ? *reinterpret_cast<const f32x4*>(g.ws + (long)r * g.N + c)
+                           : *reinterpret_cast<const f32x4*>(g.C + (long)r * g.ldc + c);
+            if (MODE == 2) zz[u] = *reinterpret_cast<const f32x4*>(g.ez + (long)r * g.ldz + c);
+        }
+        for (int s = 1; s < g.S; ++s) {
+            f32x4 w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = min(r0 + rl + 16 * u, g.M - 1);
+                w[u] = *reinterpret_cast<const f32x4*>(g.ws + (long)s * mn + (long)r * g.N + c);
             }
-            if (EPI == 2) {
-                const f32x4 zz = *reinterpret_cast<const f32x4*>(g.ez + (long)r * g.ldz + c);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[u][k] += w[u][k];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + rl + 16 * u;
+            if (r >= g.M) continue;
+            if (MODE == 2) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float xh = (zz[k] - mu[k]) * is[k];
-                    if (!(fmaf(xh, ga[k], be[k]) > 0.f)) v[k] = 0.f;
-                    s1[k] += v[k];
-                    s2[k] = fmaf(v[k], xh, s2[k]);
+                    const float xh = (zz[u][k] - mu[k]) * is[k];
+                    if (!(fmaf(xh, ga[k], be[k]) > 0.f)) v[u][k] = 0.f;
+                    s1[k] += v[u][k];
+                    s2[k] = fmaf(v[u][k], xh, s2[k]);
                 }
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float d = v[k] - sft[k];
+                    const float d = v[u][k] - sft[k];
                     s1[k] += d;
                     s2[k] = fmaf(d, d, s2[k]);
                 }
             }
-            *reinterpret_cast<f32x4*>(g.C + (long)r * g.ldc + c) = v;
+            *reinterpret_cast<f32x4*>(g.C + (long)r * g.ldc + c) = v[u];
         }
     }
 #pragma unroll
@@ -490,18 +641,21 @@ __global__ __launch_bounds__(256) void creduce_stats_kernel(CArgs g) {
     if (threadIdx.x < 128) {
         const int which = threadIdx.x >> 6, cc = threadIdx.x & 63;
         if (blockIdx.x * 64 + cc < g.N) {
-            float v = red[0][which][cc];
+            float t = red[0][which][cc];
 #pragma unroll
-            for (int i = 1; i < 16; ++i) v += red[i][which][cc];
-            g.stat_partial[((long)blockIdx.y * 2 + which) * g.N + blockIdx.x * 64 + cc] = v;
+            for (int i = 1; i < 16; ++i) t += red[i][which][cc];
+            g.stat_partial[((long)blockIdx.y * 2 + which) * g.N + blockIdx.x * 64 + cc] = t;
         }
     }
 }
 
 }  // namespace
 
+constexpr int CG_MAX_SPLIT = 128;   // wgrad of the early layers: 4 output tiles, K = 32768 rows
+int g_cgemm_vec = 1;          // LDS-transposed 16-byte C stores when the output allows it
 int g_cgemm_target = 512;     // aim for this many workgroups (tiles x splits) when the tile grid alone is < 256
 int g_cgemm_kmin = 128;       // at least this much K per split
+int g_cgemm_mi = 0;           // 0: pick the row tile (64 or 128) per shape; 1 / 2: force it (tuning)
 
 bool cgemm_supported(bool tA, bool tB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                      long sA, long sB) {
@@ -516,7 +670,38 @@ bool cgemm_supported(bool tA, bool tB, int M, int N, int K, const float* A, long
     return abytes < 0x7fffffffL && bbytes < 0x7fffffffL;
 }
 
-// pro: 0 none, 1 A prologue (needs !tA), 2 B prologue (needs !tB);  epi: 0 plain, 1 stats, 2 mask+stats.
+namespace {
+
+template <int MI, bool AMC, bool BMC, int PRO, bool G>
+void launch_ev(hipStream_t st, dim3 grid, const CArgs& g, int kepi, bool vec) {
+    dim3 block(256);
+    if (kepi == 1) hipLaunchKernelGGL((cgemm_kernel<MI, AMC, BMC, PRO, 1, G, true>), grid, block, 0, st, g);
+    else if (vec)  hipLaunchKernelGGL((cgemm_kernel<MI, AMC, BMC, PRO, 0, G, true>), grid, block, 0, st, g);
+    else           hipLaunchKernelGGL((cgemm_kernel<MI, AMC, BMC, PRO, 0, G, false>), grid, block, 0, st, g);
+}
+
+template <int MI>
+int launch_layout(hipStream_t st, dim3 grid, const CArgs& g, bool tA, bool tB, int pro, int kepi, bool gather, bool vec) {
+    if (!tA && tB) {            // forward of a 1x1 convolution, nn.Linear: both k-contiguous
+        if (gather) { if (pro == 1) launch_ev<MI, false, false, 1, true>(st, grid, g, kepi, vec); else launch_ev<MI, false, false, 0, true>(st, grid, g, kepi, vec); }
+        else        { if (pro == 1) launch_ev<MI, false, false, 1, false>(st, grid, g, kepi, vec); else launch_ev<MI, false, false, 0, false>(st, grid, g, kepi, vec); }
+    } else if (!tA && !tB) {    // dgrad: A k-contiguous, B [K][N]
+        SCN_ARG(!gather && pro == 0, "cgemm: NN product takes no gather / prologue");
+        launch_ev<MI, false, true, 0, false>(st, grid, g, kepi, vec);
+    } else if (tA && !tB) {     // wgrad: A [K][M], B [K][N]
+        SCN_ARG(kepi == 0, "cgemm: TN product takes no statistics epilogue");
+        if (gather) { if (pro == 2) launch_ev<MI, true, true, 2, true>(st, grid, g, 0, vec); else launch_ev<MI, true, true, 0, true>(st, grid, g, 0, vec); }
+        else        { if (pro == 2) launch_ev<MI, true, true, 2, false>(st, grid, g, 0, vec); else launch_ev<MI, true, true, 0, false>(st, grid, g, 0, vec); }
+    } else {
+        SCN_ARG(!gather && pro == 0 && kepi == 0, "cgemm: TT product is plain");
+        launch_ev<MI, true, false, 0, false>(st, grid, g, 0, vec);
+    }
+    return 0;
+}
+
+}  // namespace
+
+// pro: 0 none, 1 A prologue (needs !tA), 2 B prologue (needs tA && !tB);  epi: 0 plain, 1 stats, 2 mask + BN-backward sums.
 int cgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, const float* A, long lda, const float* B,
           long ldb, float beta, float* C, long ldc, const float* bias, const float* rowmask, int batch, long sA, long sB,
           long sC, float* ws, long ws_floats, const ConvExtra* ex) {
@@ -528,26 +713,33 @@ int cgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
     const bool gather = ex && ex->stride > 1;
     SCN_ARG(pro == 0 || (pro == 1 && !tA) || (pro == 2 && !tB && tA), "cgemm: prologue / layout mismatch");
     SCN_ARG(epi == 0 || (batch == 1 && beta == 0.f && !bias && !rowmask && ex->stat_partial), "cgemm: statistics epilogue needs a plain product");
-    SCN_ARG(epi != 2 || (ex->ez && ex->emean && ex->einvstd && ex->egamma && ex->ebeta && N % 4 == 0 && ex->ldz % 4 == 0),
-            "cgemm: mask epilogue arguments");
+    SCN_ARG(epi != 2 || (ex->ez && ex->emean && ex->einvstd && ex->egamma && ex->ebeta && ex->ldz % 4 == 0), "cgemm: mask epilogue arguments");
     SCN_ARG(pro == 0 || ex->pro_ss, "cgemm: prologue table");
     SCN_ARG(!gather || (ex->Hi > 0 && ex->Wi > 0 && ex->Ho > 0 && ex->Wo > 0 && batch == 1), "cgemm: gather geometry");
-    const int mt = cdiv(M, TM), nt = cdiv(N, TN);
+    const bool vec = g_cgemm_vec && N % 4 == 0 && ldc % 4 == 0 && sC % 4 == 0 && aligned16(C) &&
+                     ((long)(M - 1) * ldc + N) * 4 < 0x7fffffffL && (long)M * N * 4 < 0x7fffffffL;
+    SCN_ARG(epi == 0 || vec, "cgemm: the statistics epilogues need N % 4 == 0, ldc % 4 == 0 and a 16-byte aligned C");
+    // row tile: 64 rows when the 128-row grid alone cannot give every CU a workgroup but the 64-row grid can come closer
+    const int nt = cdiv(N, TN);
+    int mi = 2;
+    if ((long)cdiv(M, 128) * nt * batch < 256 && M > 64) mi = 1;
+    if (g_cgemm_mi == 1 || g_cgemm_mi == 2) mi = g_cgemm_mi;
+    if (ex && ex->force_mi > 0) mi = ex->force_mi;
+    const int tmrows = 64 * mi, mt = cdiv(M, tmrows);
     const long tiles = (long)mt * nt * batch;
     int S = 1;
-    if (ws && tiles < 256 && K >= 2 * g_cgemm_kmin) {
+    if (ws && tiles < 224 && K >= 2 * g_cgemm_kmin) {
         S = (int)((g_cgemm_target + tiles - 1) / tiles);
         const int smax = K / g_cgemm_kmin;
         if (S > smax) S = smax;
-        if (S > SCN_MAX_KSPLIT) S = SCN_MAX_KSPLIT;
+        if (S > CG_MAX_SPLIT) S = CG_MAX_SPLIT;
         while (S > 1 && (long)S * batch * M * N > ws_floats) --S;
         if (S < 1) S = 1;
     }
     if (ex && ex->force_split > 0) {
         S = ex->force_split;
-        SCN_ARG(S == 1 || (ws && (long)S * batch * M * N <= ws_floats && S <= SCN_MAX_KSPLIT), "cgemm: forced split does not fit");
+        SCN_ARG(S == 1 || (ws && (long)S * batch * M * N <= ws_floats && S <= CG_MAX_SPLIT), "cgemm: forced split does not fit");
     }
-    if (epi && S > 1) SCN_ARG(N % 4 == 0 && ldc % 4 == 0, "cgemm: split-K statistics epilogue needs N % 4 == 0");
     int kper = cdiv(K, S);
     kper = (kper + TK - 1) / TK * TK;
     S = cdiv(K, kper);
@@ -562,35 +754,26 @@ int cgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
         g.ez = ex->ez; g.emean = ex->emean; g.einvstd = ex->einvstd; g.egamma = ex->egamma; g.ebeta = ex->ebeta; g.ldz = ex->ldz;
     }
     dim3 grid(mt * nt, batch * S), block(256);
-    const int kepi = S > 1 ? 0 : epi;     // with split-K the reduce kernel carries the epilogue
-#define SCN_CG(AMC, BMC, PRO_, EPI_, G_) hipLaunchKernelGGL((cgemm_kernel<AMC, BMC, PRO_, EPI_, G_>), grid, block, 0, st, g)
-    if (!tA && tB) {            // forward of a 1x1 convolution, nn.Linear: both k-contiguous
-        if (gather) { if (pro == 1) { if (kepi == 1) SCN_CG(false, false, 1, 1, true); else SCN_CG(false, false, 1, 0, true); }
-                      else { if (kepi == 1) SCN_CG(false, false, 0, 1, true); else SCN_CG(false, false, 0, 0, true); } }
-        else if (pro == 1) { if (kepi == 1) SCN_CG(false, false, 1, 1, false); else SCN_CG(false, false, 1, 0, false); }
-        else { if (kepi == 1) SCN_CG(false, false, 0, 1, false); else if (kepi == 2) SCN_CG(false, false, 0, 2, false); else SCN_CG(false, false, 0, 0, false); }
-    } else if (!tA && !tB) {    // dgrad: A k-contiguous, B [K][N]
-        SCN_ARG(!gather && pro == 0, "cgemm: NN product takes no gather / prologue");
-        if (kepi == 2) SCN_CG(false, true, 0, 2, false); else if (kepi == 1) SCN_CG(false, true, 0, 1, false); else SCN_CG(false, true, 0, 0, false);
-    } else if (tA && !tB) {     // wgrad: A [K][M], B [K][N]
-        SCN_ARG(kepi == 0, "cgemm: TN product takes no statistics epilogue");
-        if (gather) { if (pro == 2) SCN_CG(true, true, 2, 0, true); else SCN_CG(true, true, 0, 0, true); }
-        else { if (pro == 2) SCN_CG(true, true, 2, 0, false); else SCN_CG(true, true, 0, 0, false); }
-    } else {
-        SCN_ARG(!gather && pro == 0 && kepi == 0, "cgemm: TT product is plain");
-        SCN_CG(true, false, 0, 0, false);
-    }
-#undef SCN_CG
+    // in-kernel: plain or statistics; the mask pass (epi 2) and every epilogue of a split product run in the second launch
+    const int kepi = (S > 1 || epi == 2) ? 0 : epi;
+    if (mi == 2) SCN_TRY(launch_layout<2>(st, grid, g, tA, tB, pro, kepi, gather, vec));
+    else         SCN_TRY(launch_layout<1>(st, grid, g, tA, tB, pro, kepi, gather, vec));
     SCN_LAUNCH_CHECK();
-    if (S > 1) {
-        if (epi == 1) hipLaunchKernelGGL(creduce_stats_kernel<1>, dim3(cdiv(N, 64), mt), block, 0, st, g);
-        else if (epi == 2) hipLaunchKernelGGL(creduce_stats_kernel<2>, dim3(cdiv(N, 64), mt), block, 0, st, g);
-        else hipLaunchKernelGGL(creduce_kernel, dim3(cdiv((long)M * N, 256), batch), block, 0, st, g);
+    if (S > 1 || epi == 2) {
+        if (epi == 0) {
+            if (vec) hipLaunchKernelGGL(creduce_kernel<true>, dim3(cdiv((long)M * N / 4, 256), batch), block, 0, st, g);
+            else     hipLaunchKernelGGL(creduce_kernel<false>, dim3(cdiv((long)M * N, 256), batch), block, 0, st, g);
+        } else {
+            if (S == 1) g.S = 0;      // un-split mask pass: read the product back from C
+            dim3 sgrid(cdiv(N, 64), cdiv(M, SROWS));
+            if (epi == 1) hipLaunchKernelGGL(cstats_kernel<1>, sgrid, block, 0, st, g);
+            else          hipLaunchKernelGGL(cstats_kernel<2>, sgrid, block, 0, st, g);
+        }
         SCN_LAUNCH_CHECK();
     }
     return 0;
 }
 
-int cgemm_row_tiles(int M) { return cdiv(M, TM); }
+int cgemm_row_tiles(int M) { return cdiv(M, SROWS); }
 
 }  // namespace scn

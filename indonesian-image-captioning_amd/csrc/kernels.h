@@ -22,7 +22,7 @@ int sgemm_ws(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha,
 // ---- cgemm.hip: LDS-DMA pipelined fp32 GEMM with the 1x1-convolution prologues / epilogues -------------------
 struct ConvExtra {
     int pro = 0;              // 1: A = relu(A*scale[k]+shift[k]) (k-contiguous A); 2: B = relu(B*scale[n]+shift[n]) ([K][N] B)
-    int epi = 0;              // 1: column sums of (y-s), (y-s)^2 per 128-row tile; 2: relu mask from z + sums of g, g*xhat
+    int epi = 0;              // 1: column sums of (y-s), (y-s)^2 per 64 rows; 2: relu mask from z + sums of g, g*xhat
     const float* pro_ss = nullptr;    // interleaved {scale, shift} per channel
     float* stat_partial = nullptr;    // [row tiles][2][N]
     const float* stat_shift = nullptr;
@@ -30,6 +30,7 @@ struct ConvExtra {
     const float* egamma = nullptr; const float* ebeta = nullptr; long ldz = 0;
     int stride = 1, Hi = 0, Wi = 0, Ho = 0, Wo = 0;   // stride > 1: rows of the activation operand are gathered
     int force_split = 0;      // tests / tuning: > 0 forces the split-K factor
+    int force_mi = 0;         // tests / tuning: 1 / 2 forces the 64- / 128-row tile
 };
 bool cgemm_supported(bool tA, bool tB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                      long sA, long sB);
@@ -146,7 +147,10 @@ int reduce_slabs(hipStream_t st, int rows, int N, Slabs s, float* out);
 // ---- batchnorm.hip (channels-last feature maps as [R = N*H*W, C] matrices) --------------------------
 int bn_max_chunks();
 int bn_stats(hipStream_t st, int R, int C, const void* x, int bf16, float eps, float momentum, float* partial,
-             float* mean, float* invstd, float* run_mean, float* run_var);
+             float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma = nullptr,
+             const float* beta = nullptr, float* ss_out = nullptr);
+int bn_bwd_dx(hipStream_t st, int R, int C, const float* g, const float* z, const float* mean, const float* invstd,
+              const float* gamma, const float* dbeta, const float* dgamma, float* dz);
 int bn_apply(hipStream_t st, int R, int C, const void* z, const void* res, int bf16, const float* mean,
              const float* invstd, const float* gamma, const float* beta, int relu, void* y);
 int bn_bwd(hipStream_t st, int R, int C, const void* dy, const void* y, const void* z, int bf16, const float* mean,

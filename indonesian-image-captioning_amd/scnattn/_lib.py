@@ -50,7 +50,7 @@ class ConvExtra(C.Structure):      # scnattn_conv_extra
                 ("stat_partial", C.c_void_p), ("stat_shift", C.c_void_p), ("ez", C.c_void_p), ("emean", C.c_void_p),
                 ("einvstd", C.c_void_p), ("egamma", C.c_void_p), ("ebeta", C.c_void_p), ("ldz", C.c_long),
                 ("stride", C.c_int), ("Hi", C.c_int), ("Wi", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int),
-                ("force_split", C.c_int)]
+                ("force_split", C.c_int), ("force_mi", C.c_int)]
 
 
 _SIGS = {
@@ -69,10 +69,12 @@ _SIGS = {
                        vp, i64, C.POINTER(ConvExtra)], i32),
     "scnattn_cgemm_row_tiles": ([i32], i32),
     "scnattn_conv1x1_fwd": ([vp, i32, i32, i32, vp, vp, vp, C.POINTER(ConvExtra), vp, i64], i32),
-    "scnattn_conv1x1_dgrad": ([vp, i32, i32, i32, vp, vp, f32, vp, C.POINTER(ConvExtra), vp, i64], i32),
+    "scnattn_conv1x1_dgrad": ([vp, i32, i32, i32, vp, vp, i32, f32, vp, C.POINTER(ConvExtra), vp, i64], i32),
     "scnattn_conv1x1_wgrad": ([vp, i32, i32, i32, vp, vp, vp, C.POINTER(ConvExtra), vp, i64], i32),
     "scnattn_bn_finalize": ([vp, i64, i32, i32, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp], i32),
     "scnattn_bn_bwd_finalize": ([vp, i32, i32, vp, vp, vp], i32),
+    "scnattn_bn_stats_fold": ([vp, i32, i32, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp], i32),
+    "scnattn_bn_bwd_dx": ([vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp], i32),
     "scnattn_skinny_gemm": ([vp, i32, i32, i32, i32, vp, i64, i64, vp, i64, i64, vp, i64, i64, i64, i32,
                              C.POINTER(i32)], i32),
     "scnattn_attn_scores": ([vp, i32, i32, i32, vp, vp, i32, i64, i64, vp, vp, vp, vp, vp], i32),

@@ -1,0 +1,295 @@
+"""Fused Bottleneck of the ResNet-152 trunk on MI355X (fp32, channels-last), one autograd node per block.
+
+torchvision's Bottleneck behind the reference's encoder (models/encoders/caption.py:17-22) is
+    out = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) + identity),   identity = x | bn_d(conv_d(x))
+with conv1 / conv3 / conv_d 1x1 and conv2 3x3.  On channels-last maps a 1x1 convolution is the GEMM
+[R = N*H*W, Cin] x [Cin, Cout]; this module runs every 1x1 convolution -- forward, d input, d weight -- on the
+hand-written LDS-DMA pipelined MFMA kernel of csrc/cgemm.hip and lets the BatchNorm work ride on it:
+
+  forward   conv1  + statistics epilogue (sum, sum^2 of z1 per channel)      -> no bn1 statistics pass
+            bn1 apply + relu -> a1 (materialised: the 3x3 conv2 is MIOpen's and needs it)
+            conv2 (MIOpen) -> z2 ; bn2 statistics pass (also writes the folded scale/shift)
+            conv3 with the bn2+relu PROLOGUE on its input operand (a2 is never written or read)
+                  + statistics epilogue for bn3                                 -> no bn2 apply, no bn3 statistics pass
+            bn3 apply + identity + relu -> out
+  backward  bn3 (two passes, as before) -> dz3, d identity
+            conv3 wgrad with the bn2+relu prologue on its activation operand (a2 recomputed on load)
+            conv3 dgrad with the MASK epilogue: g2 = d a2 * [a2 > 0] + the two bn2-backward column sums
+                                                                                -> no bn2 reduction pass
+            bn2 element-wise half -> dz2 ; conv2 backward (MIOpen) ; bn1 backward (two passes)
+            conv1 wgrad ; conv1 dgrad ACCUMULATING into d identity (beta = 1)   -> no residual-gradient add kernel
+What stays a separate pass is what a 3x3 MIOpen convolution forces (it needs materialised, normalised inputs).
+The strided 1x1 downsample convolution gathers its input rows inside the kernel.
+
+`Bottleneck.forward` (scnattn/resnet.py) calls `bottleneck()` for fp32 CUDA inputs in training mode; everything else
+(eval mode, bf16 autocast, CPU structure tests) takes the unfused module path."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvExtra
+
+ENABLED = True          # class-wide switch: tests / A-B runs compare against the unfused path
+
+_bufs = {}
+
+
+def _buffers(dev):
+    """Per-device scratch, reused in stream order: split-K slabs of the GEMMs and the statistics partials."""
+    b = _bufs.get(dev)
+    if b is None:
+        b = _bufs[dev] = (torch.empty(16 << 20, device=dev, dtype=torch.float32),     # 64 MiB split-K slabs
+                          torch.empty(2 << 20, device=dev, dtype=torch.float32),      # [64-row blocks][2][C] partials
+                          torch.empty(2 << 20, device=dev, dtype=torch.float32))      # BN chunk partials (bn_stats)
+    return b
+
+
+_fn = None
+
+
+def _fns():
+    global _fn
+    if _fn is None:
+        h = _lib.lib()
+        _fn = (h, torch._C._cuda_getCurrentRawStream)
+    return _fn
+
+
+def _chk(rc, what):
+    if rc:
+        _lib.check(rc, what)
+
+
+def _as2d(t4):
+    """(N, C, H, W) channels-last -> its [N*H*W, C] matrix view (no copy)."""
+    n, c, h, w = t4.shape
+    return t4.permute(0, 2, 3, 1).reshape(n * h * w, c)
+
+
+def _as4d(t2, n, h, w):
+    """[N*H*W, C] -> the (N, C, H, W) channels-last view MIOpen takes (no copy)."""
+    return t2.view(n, h, w, t2.shape[1]).permute(0, 3, 1, 2)
+
+
+class _Ctx:
+    pass
+
+
+def _conv_fwd(h, st, x2, w2, R, Cin, Cout, ws, ex):
+    y = torch.empty((R, Cout), device=x2.device, dtype=torch.float32)
+    _chk(h.scnattn_conv1x1_fwd(st, R, Cin, Cout, x2.data_ptr(), w2.data_ptr(), y.data_ptr(), C.byref(ex), ws.data_ptr(),
+                               ws.numel()), "scnattn_conv1x1_fwd")
+    return y
+
+
+def _finalize(h, st, R, Cn, part, bn_mod, training, gamma, beta, want_ss):
+    dev = part.device
+    stats = torch.empty((2, Cn), device=dev, dtype=torch.float32)
+    ss = torch.empty((Cn, 2), device=dev, dtype=torch.float32) if want_ss else None
+    mt = h.scnattn_cgemm_row_tiles(R)
+    _chk(h.scnattn_bn_finalize(st, R, Cn, mt, part.data_ptr(), bn_mod.running_mean.data_ptr(), bn_mod.eps,
+                               bn_mod.momentum, stats[0].data_ptr(), stats[1].data_ptr(),
+                               bn_mod.running_mean.data_ptr(), bn_mod.running_var.data_ptr(),
+                               gamma.data_ptr() if want_ss else None, beta.data_ptr() if want_ss else None,
+                               ss.data_ptr() if want_ss else None), "scnattn_bn_finalize")
+    return stats, ss
+
+
+def _wt(h, st, w, cout, cin):
+    """[Cout][Cin] 1x1 weight -> [Cin][Cout] (<= 4 MB, one small kernel): conv1's d input then runs with both operands
+    on the k-contiguous LDS image (a [K][N] weight with N = Cin large is the slow layout: 56 vs 40 us on layer3)."""
+    wt = torch.empty((cin, cout), device=w.device, dtype=torch.float32)
+    _chk(h.scnattn_transpose2d(st, cout, cin, w.data_ptr(), cin, wt.data_ptr(), cout), "scnattn_transpose2d")
+    return wt
+
+
+class _BottleneckFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, x, w1, g1, b1, w2, g2, b2, w3, g3, b3, wd, gd, bd):
+        h, raw_stream = _fns()
+        dev = x.device
+        st = raw_stream(dev.index)
+        ws, part, bnpart = _buffers(dev)
+        if not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)
+        N, Cin, Hi, Wi = x.shape
+        p = w1.shape[0]
+        C4 = w3.shape[0]
+        s = mod.stride
+        Ho, Wo = (Hi - 1) // s + 1, (Wi - 1) // s + 1
+        Rin, Rout = N * Hi * Wi, N * Ho * Wo
+        x2 = _as2d(x)
+        bn1, bn2, bn3 = mod.bn1, mod.bn2, mod.bn3
+        # conv1 (+ bn1 statistics)
+        ex = ConvExtra(epi=1, stat_partial=part.data_ptr(), stat_shift=bn1.running_mean.data_ptr())
+        z1 = _conv_fwd(h, st, x2, w1.view(p, Cin), Rin, Cin, p, ws, ex)
+        st1, _ = _finalize(h, st, Rin, p, part, bn1, True, g1, b1, False)
+        a1 = torch.empty_like(z1)
+        _chk(h.scnattn_bn_apply(st, Rin, p, z1.data_ptr(), None, 0, st1[0].data_ptr(), st1[1].data_ptr(), g1.data_ptr(),
+                                b1.data_ptr(), 1, a1.data_ptr()), "scnattn_bn_apply")
+        # conv2 (3x3, MIOpen) + bn2 statistics pass with the folded scale/shift
+        z2_4 = torch.ops.aten.convolution(_as4d(a1, N, Hi, Wi), w2, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1)
+        if not z2_4.is_contiguous(memory_format=torch.channels_last):
+            z2_4 = z2_4.contiguous(memory_format=torch.channels_last)
+        z2 = _as2d(z2_4)
+        st2 = torch.empty((2, p), device=dev, dtype=torch.float32)
+        ss2 = torch.empty((p, 2), device=dev, dtype=torch.float32)
+        _chk(h.scnattn_bn_stats_fold(st, Rout, p, z2.data_ptr(), bn2.eps, bn2.momentum, bnpart.data_ptr(),
+                                     st2[0].data_ptr(), st2[1].data_ptr(), bn2.running_mean.data_ptr(),
+                                     bn2.running_var.data_ptr(), g2.data_ptr(), b2.data_ptr(), ss2.data_ptr()),
+             "scnattn_bn_stats_fold")
+        # conv3 with the bn2+relu prologue (+ bn3 statistics)
+        ex = ConvExtra(pro=1, epi=1, pro_ss=ss2.data_ptr(), stat_partial=part.data_ptr(),
+                       stat_shift=bn3.running_mean.data_ptr())
+        z3 = _conv_fwd(h, st, z2, w3.view(C4, p), Rout, p, C4, ws, ex)
+        st3, _ = _finalize(h, st, Rout, C4, part, bn3, True, g3, b3, False)
+        # identity
+        zd = std = None
+        if wd is not None:
+            bnd = mod.downsample[1]
+            ex = ConvExtra(epi=1, stat_partial=part.data_ptr(), stat_shift=bnd.running_mean.data_ptr(),
+                           stride=s, Hi=Hi, Wi=Wi, Ho=Ho, Wo=Wo)
+            zd = _conv_fwd(h, st, x2, wd.view(C4, Cin), Rout, Cin, C4, ws, ex)
+            std, _ = _finalize(h, st, Rout, C4, part, bnd, True, gd, bd, False)
+            idn = torch.empty_like(zd)
+            _chk(h.scnattn_bn_apply(st, Rout, C4, zd.data_ptr(), None, 0, std[0].data_ptr(), std[1].data_ptr(),
+                                    gd.data_ptr(), bd.data_ptr(), 0, idn.data_ptr()), "scnattn_bn_apply")
+        else:
+            idn = x2
+        out = torch.empty((Rout, C4), device=dev, dtype=torch.float32)
+        _chk(h.scnattn_bn_apply(st, Rout, C4, z3.data_ptr(), idn.data_ptr(), 0, st3[0].data_ptr(), st3[1].data_ptr(),
+                                g3.data_ptr(), b3.data_ptr(), 1, out.data_ptr()), "scnattn_bn_apply")
+        ctx.geom = (N, Cin, Hi, Wi, p, C4, s, Ho, Wo)
+        ctx.has_down = wd is not None
+        ctx.save_for_backward(x, w1, g1, b1, w2, g2, b2, w3, g3, b3, wd, gd, bd, z1, a1, z2, z3, out, zd, st1, st2, ss2,
+                              st3, std)
+        return _as4d(out, N, Ho, Wo)
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, raw_stream = _fns()
+        (x, w1, g1, b1, w2, g2, b2, w3, g3, b3, wd, gd, bd, z1, a1, z2, z3, out, zd, st1, st2, ss2, st3,
+         std) = ctx.saved_tensors
+        N, Cin, Hi, Wi, p, C4, s, Ho, Wo = ctx.geom
+        dev = x.device
+        st = raw_stream(dev.index)
+        ws, part, bnpart = _buffers(dev)
+        Rin, Rout = N * Hi * Wi, N * Ho * Wo
+        need = ctx.needs_input_grad      # (mod, x, w1, g1, b1, w2, g2, b2, w3, g3, b3, wd, gd, bd)
+        if dout.dtype != torch.float32 or not dout.is_contiguous(memory_format=torch.channels_last):
+            dout = dout.float().contiguous(memory_format=torch.channels_last)
+        dout2 = _as2d(dout)
+        x2 = _as2d(x)
+        f32 = dict(device=dev, dtype=torch.float32)
+        # ---- bn3 (+ identity + relu) backward: dz3, d identity ------------------------------------------------
+        dz3 = torch.empty((Rout, C4), **f32)
+        need_res = need[1] or ctx.has_down
+        dres = torch.empty((Rout, C4), **f32) if need_res else None
+        dgb3 = torch.empty((2, C4), **f32)
+        _chk(h.scnattn_bn_bwd(st, Rout, C4, dout2.data_ptr(), out.data_ptr(), z3.data_ptr(), 0, st3[0].data_ptr(),
+                              st3[1].data_ptr(), g3.data_ptr(), None, 1, 1, bnpart.data_ptr(), dgb3[0].data_ptr(),
+                              dgb3[1].data_ptr(), dz3.data_ptr(), None if dres is None else dres.data_ptr()),
+             "scnattn_bn_bwd")
+        # ---- conv3: wgrad with a2 recomputed on load, dgrad with the bn2 mask / reduction epilogue ----------------
+        dw3 = None
+        if need[8]:
+            dw3 = torch.empty_like(w3)
+            ex = ConvExtra(pro=2, pro_ss=ss2.data_ptr())
+            _chk(h.scnattn_conv1x1_wgrad(st, Rout, p, C4, dz3.data_ptr(), z2.data_ptr(), dw3.data_ptr(), C.byref(ex),
+                                         ws.data_ptr(), ws.numel()), "scnattn_conv1x1_wgrad")
+        g2m = torch.empty((Rout, p), **f32)
+        ex = ConvExtra(epi=2, stat_partial=part.data_ptr(), ez=z2.data_ptr(), emean=st2[0].data_ptr(),
+                       einvstd=st2[1].data_ptr(), egamma=g2.data_ptr(), ebeta=b2.data_ptr(), ldz=p)
+        _chk(h.scnattn_conv1x1_dgrad(st, Rout, p, C4, dz3.data_ptr(), w3.data_ptr(), 0, 0.0, g2m.data_ptr(), C.byref(ex),
+                                     ws.data_ptr(), ws.numel()), "scnattn_conv1x1_dgrad")
+        dgb2 = torch.empty((2, p), **f32)
+        _chk(h.scnattn_bn_bwd_finalize(st, p, h.scnattn_cgemm_row_tiles(Rout), part.data_ptr(), dgb2[0].data_ptr(),
+                                       dgb2[1].data_ptr()), "scnattn_bn_bwd_finalize")
+        dz2 = torch.empty((Rout, p), **f32)
+        _chk(h.scnattn_bn_bwd_dx(st, Rout, p, g2m.data_ptr(), z2.data_ptr(), st2[0].data_ptr(), st2[1].data_ptr(),
+                                 g2.data_ptr(), dgb2[0].data_ptr(), dgb2[1].data_ptr(), dz2.data_ptr()), "scnattn_bn_bwd_dx")
+        del g2m
+        # ---- conv2 (MIOpen) -------------------------------------------------------------------------------------
+        da1_4, dw2, _ = torch.ops.aten.convolution_backward(_as4d(dz2, N, Ho, Wo), _as4d(a1, N, Hi, Wi), w2, None, [s, s],
+                                                            [1, 1], [1, 1], False, [0, 0], 1, [True, bool(need[5]), False])
+        if not da1_4.is_contiguous(memory_format=torch.channels_last):
+            da1_4 = da1_4.contiguous(memory_format=torch.channels_last)
+        da1 = _as2d(da1_4)
+        # ---- bn1 (+ relu, mask recomputed from z1) ----------------------------------------------------------------
+        need_dx = need[1]
+        dz1 = torch.empty((Rin, p), **f32)
+        dgb1 = torch.empty((2, p), **f32)
+        _chk(h.scnattn_bn_bwd(st, Rin, p, da1.data_ptr(), None, z1.data_ptr(), 0, st1[0].data_ptr(), st1[1].data_ptr(),
+                              g1.data_ptr(), b1.data_ptr(), 1, 1, bnpart.data_ptr(), dgb1[0].data_ptr(), dgb1[1].data_ptr(),
+                              dz1.data_ptr(), None), "scnattn_bn_bwd")
+        dw1 = None
+        if need[2]:
+            dw1 = torch.empty_like(w1)
+            _chk(h.scnattn_conv1x1_wgrad(st, Rin, Cin, p, dz1.data_ptr(), x2.data_ptr(), dw1.data_ptr(), None,
+                                         ws.data_ptr(), ws.numel()), "scnattn_conv1x1_wgrad")
+        # ---- identity branch and d x --------------------------------------------------------------------------------
+        dwd = dgbd = None
+        dx = None
+        if ctx.has_down:
+            dzd = torch.empty((Rout, C4), **f32)
+            dgbd = torch.empty((2, C4), **f32)
+            _chk(h.scnattn_bn_bwd(st, Rout, C4, dres.data_ptr(), None, zd.data_ptr(), 0, std[0].data_ptr(),
+                                  std[1].data_ptr(), gd.data_ptr(), None, 0, 1, bnpart.data_ptr(), dgbd[0].data_ptr(),
+                                  dgbd[1].data_ptr(), dzd.data_ptr(), None), "scnattn_bn_bwd")
+            if need[11]:
+                dwd = torch.empty_like(wd)
+                ex = ConvExtra(stride=s, Hi=Hi, Wi=Wi, Ho=Ho, Wo=Wo)
+                _chk(h.scnattn_conv1x1_wgrad(st, Rout, Cin, C4, dzd.data_ptr(), x2.data_ptr(), dwd.data_ptr(),
+                                             C.byref(ex), ws.data_ptr(), ws.numel()), "scnattn_conv1x1_wgrad")
+            if need_dx:
+                dx = torch.empty((Rin, Cin), **f32)
+                _chk(h.scnattn_conv1x1_dgrad(st, Rin, Cin, p, dz1.data_ptr(), _wt(h, st, w1, p, Cin).data_ptr(), 1, 0.0,
+                                             dx.data_ptr(), None, ws.data_ptr(), ws.numel()), "scnattn_conv1x1_dgrad")
+                dxd = torch.empty((Rout, Cin), **f32)
+                _chk(h.scnattn_conv1x1_dgrad(st, Rout, Cin, C4, dzd.data_ptr(), wd.data_ptr(), 0, 0.0, dxd.data_ptr(), None,
+                                             ws.data_ptr(), ws.numel()), "scnattn_conv1x1_dgrad")
+                # scatter the strided rows back (2 of the 50 blocks need this: layer3.0, layer4.0)
+                dx.view(N, Hi, Wi, Cin)[:, ::s, ::s].add_(dxd.view(N, Ho, Wo, Cin))
+        elif need_dx:
+            # d x = d identity + dz1 . W1, accumulated in place (beta = 1): no residual-gradient add kernel
+            dx = dres
+            _chk(h.scnattn_conv1x1_dgrad(st, Rin, Cin, p, dz1.data_ptr(), _wt(h, st, w1, p, Cin).data_ptr(), 1, 1.0,
+                                         dx.data_ptr(), None, ws.data_ptr(), ws.numel()), "scnattn_conv1x1_dgrad")
+        dx4 = _as4d(dx, N, Hi, Wi) if dx is not None else None
+        return (None, dx4, dw1, dgb1[1] if need[3] else None, dgb1[0] if need[4] else None,
+                dw2 if need[5] else None, dgb2[1] if need[6] else None, dgb2[0] if need[7] else None,
+                dw3, dgb3[1] if need[9] else None, dgb3[0] if need[10] else None,
+                dwd, (dgbd[1] if need[12] else None) if dgbd is not None else None,
+                (dgbd[0] if need[13] else None) if dgbd is not None else None)
+
+
+def usable(mod, x):
+    """The fused path covers what the train step runs: fp32 CUDA maps, BatchNorm in training mode with running
+    statistics and affine parameters, widths that the 16-byte LDS-DMA granules can address."""
+    if not (ENABLED and x.is_cuda and x.dtype == torch.float32 and mod.training and not torch.is_autocast_enabled()):
+        return False
+    for bn in (mod.bn1, mod.bn2, mod.bn3):
+        if bn.weight is None or not bn.track_running_stats or bn.momentum is None or bn.weight.dtype != torch.float32:
+            return False
+    p, cin = mod.conv1.weight.shape[0], mod.conv1.weight.shape[1]
+    if p % 16 or cin % 16 or mod.conv2.groups != 1 or mod.conv2.dilation != (1, 1):
+        return False
+    if mod.downsample is not None:
+        d0, d1 = mod.downsample[0], mod.downsample[1]
+        if d0.kernel_size != (1, 1) or d0.stride != (mod.stride, mod.stride) or d1.weight is None or d1.momentum is None:
+            return False
+    return True
+
+
+def bottleneck(mod, x):
+    """One fused forward of `mod` (a scnattn.resnet.Bottleneck); autograd gets a single node."""
+    for bn in (mod.bn1, mod.bn2, mod.bn3) + ((mod.downsample[1],) if mod.downsample is not None else ()):
+        if not bn.counter_managed and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+    if mod.downsample is not None:
+        wd, gd, bd = mod.downsample[0].weight, mod.downsample[1].weight, mod.downsample[1].bias
+    else:
+        wd = gd = bd = None
+    return _BottleneckFn.apply(mod, x, mod.conv1.weight, mod.bn1.weight, mod.bn1.bias, mod.conv2.weight, mod.bn2.weight,
+                               mod.bn2.bias, mod.conv3.weight, mod.bn3.weight, mod.bn3.bias, wd, gd, bd)

@@ -62,6 +62,11 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        # fp32 training-mode maps on the GPU: the whole block as ONE autograd node on the hand-written 1x1-convolution
+        # kernels with the BatchNorm statistics / normalisation fused into them (scnattn/conv.py)
+        from . import conv as _conv
+        if _conv.usable(self, x):
+            return _conv.bottleneck(self, x)
         identity = x if self.downsample is None else self.downsample(x)
         out = self.bn1(self.conv1(x), relu=True)
         out = self.bn2(self.conv2(out), relu=True)

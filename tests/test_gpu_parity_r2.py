@@ -464,3 +464,84 @@ def test_sample_beam_search_vs_oracle(dev, name, kind):
             compared += 1
     assert compared >= 4, "too few completing beams to call this a test (%d)" % compared
     _report(rep + ["%d (image, beam) cases compared" % compared], "sample() vs oracle beam search: " + name)
+
+
+# ------------------------------------------------------------------------------------------------
+# E1: the fused Bottleneck (hand-written 1x1 convolutions + BatchNorm prologues / epilogues)
+# ------------------------------------------------------------------------------------------------
+_BLOCKS = [  # (name, inplanes, planes, stride, H) -- every distinct 1x1-convolution shape of ResNet-152 at 256x256 input
+    ("layer1.0", 64, 64, 1, 64), ("layer1.1", 256, 64, 1, 64), ("layer2.0", 256, 128, 2, 64), ("layer2.1", 512, 128, 1, 32),
+    ("layer3.0", 512, 256, 2, 32), ("layer3.1", 1024, 256, 1, 16), ("layer4.0", 1024, 512, 2, 16), ("layer4.1", 2048, 512, 1, 8)]
+
+
+@pytest.mark.parametrize("name,inplanes,planes,stride,H", _BLOCKS)
+def test_fused_bottleneck_vs_fp64(dev, name, inplanes, planes, stride, H):
+    """One Bottleneck of the trunk behind models/encoders/caption.py:17-22 through scnattn/conv.py -- conv1 / conv3 /
+    downsample.0 forward, d input and d weight on csrc/cgemm.hip with the BatchNorm statistics epilogue, the
+    normalise-on-load prologue, the mask + reduction epilogue and the in-place residual-gradient accumulation --
+    against the SAME module in fp64 on the CPU (plain torch conv / batch_norm / relu): output, d x, every parameter
+    gradient, running statistics.  Also against the unfused GPU path (MIOpen convolutions + round-1 BN kernels).
+    PARITY UNPINNED against the reference's torchvision (absent from the image): this pins the kernels to the
+    public definition of the block."""
+    from scnattn.resnet import Bottleneck, FusedBatchNorm2d
+    from scnattn import conv as SC
+    from torch import nn
+    torch.manual_seed(hash(name) % 1000)
+    down = None
+    if stride != 1 or inplanes != planes * 4:
+        down = nn.Sequential(nn.Conv2d(inplanes, planes * 4, kernel_size=1, stride=stride, bias=False),
+                             FusedBatchNorm2d(planes * 4))
+    m = Bottleneck(inplanes, planes, stride, down)
+    for mod in m.modules():
+        if isinstance(mod, nn.Conv2d):
+            nn.init.kaiming_normal_(mod.weight, mode="fan_out", nonlinearity="relu")
+        elif isinstance(mod, nn.BatchNorm2d):
+            mod.weight.data.uniform_(0.5, 1.5)
+            mod.bias.data.normal_(0, 0.2)
+            mod.running_mean.normal_(0, 0.1)
+            mod.running_var.uniform_(0.8, 1.2)
+    m.train()
+    N = 4
+    x = torch.relu(torch.randn(N, inplanes, H, H)) + 0.1 * torch.randn(N, inplanes, H, H)
+    ref = copy.deepcopy(m).double()
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)
+    wgt = torch.randn_like(yr)
+    (yr * wgt).sum().backward()
+    res = {}
+    for fused in (True, False):
+        g = copy.deepcopy(m).to(dev).to(memory_format=torch.channels_last).train()
+        xg = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        SC.ENABLED = fused
+        try:
+            assert SC.usable(g, xg) == fused
+            y = g(xg)
+            (y * wgt.float().to(dev)).sum().backward()
+        finally:
+            SC.ENABLED = True
+        res[fused] = (y.detach(), xg.grad.detach(), {k: p.grad.detach() for k, p in g.named_parameters()},
+                      {k: b.detach().clone() for k, b in g.named_buffers()})
+    rep = []
+    for fused in (True, False):
+        y, dx, gr, bufs = res[fused]
+        tag = "fused" if fused else "unfused"
+        rep.append("%s %s: out %.2e  dx %.2e (l2 %.2e)" % (name, tag, rel_err(y, yr), rel_err(dx, xr.grad), rel_l2(dx, xr.grad)))
+        for k, p in ref.named_parameters():
+            rep.append("   %-24s %s grad l2 %.2e max %.2e" % (k, tag, rel_l2(gr[k], p.grad), rel_err(gr[k], p.grad)))
+    _report(rep, "fused bottleneck " + name)
+    y, dx, gr, bufs = res[True]
+    _ok(y, yr, 2e-5, "output")
+    # a ReLU pre-activation within fp32 rounding of 0 flips its mask bit and moves single gradient elements; the l2
+    # norm bounds how many may do so (none should at these sizes) and the max-norm bound is the fp32 tolerance
+    assert rel_l2(dx, xr.grad) <= 1e-4, "d x l2 %.3e" % rel_l2(dx, xr.grad)
+    for k, p in ref.named_parameters():
+        assert rel_l2(gr[k], p.grad) <= 2e-4, "%s grad l2 %.3e" % (k, rel_l2(gr[k], p.grad))
+    for k, b in ref.named_buffers():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert rel_err(bufs[k], b) <= 2e-5, k
+        elif k.endswith("num_batches_tracked"):
+            assert int(bufs[k]) == int(b) == 1, k
+    # and the fused path is no worse than the unfused one (MIOpen convolutions + separate BN passes)
+    yu, dxu, gru, _ = res[False]
+    assert rel_err(y, yr) <= max(2e-6, 3 * rel_err(yu, yr))
+    assert rel_l2(dx, xr.grad) <= max(2e-6, 3 * rel_l2(dxu, xr.grad))

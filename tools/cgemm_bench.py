@@ -16,7 +16,7 @@ from scnattn._lib import call, ptr, stream_of, ConvExtra, lib
 
 torch.backends.cudnn.benchmark = True
 dev = torch.device("cuda:0")
-WS = torch.empty(16 << 20, device=dev)
+WS = torch.empty(48 << 20, device=dev)
 
 
 def t_us(fn, it=20):
@@ -51,9 +51,10 @@ def check():
         sc = (1 + 0.5 * torch.randn(Cin, generator=g)).to(dev); sh = (0.2 * torch.randn(Cin, generator=g)).to(dev)
         ss = torch.stack([sc, sh], dim=1).contiguous()
         xd, wd, dyd = x.double(), w.double(), dy.double()
-        for split in (0, 1, 2, 4):
+        for split, mi in ((0, 0), (1, 1), (1, 2), (2, 1), (2, 2), (4, 0)):
             if split > 1 and Cin // split < 16:
                 continue
+            SF.set_option("cgemm_mi", mi)
             # fwd plain
             ex = ConvExtra(force_split=split)
             y = cgemm(x, w, False, True, torch.empty(R, Cout, device=dev), R, Cout, Cin, ex)
@@ -97,6 +98,7 @@ def check():
                 ex = ConvExtra(pro=2, pro_ss=ss.data_ptr(), force_split=split)
                 dw = cgemm(dy, x, True, False, torch.empty(Cout, Cin, device=dev), Cout, Cin, R, ex)
                 e = rel(dw, dyd.t() @ a_ref); worst = max(worst, e); assert e < 1e-5, ("wgrad pro", R, Cin, Cout, split, e)
+    SF.set_option("cgemm_mi", 0)
     # strided gather (downsample.0: 1x1, stride 2)
     Bn, Hi, Cin, Cout = 3, 8, 64, 128
     xm = torch.randn(Bn, Hi, Hi, Cin, generator=g).to(dev); w = (0.1 * torch.randn(Cout, Cin, generator=g)).to(dev)
@@ -171,9 +173,43 @@ def timeit():
               % (M, N, K, ta, tb, t0, fl / t0 / 1e6, t1, fl / t1 / 1e6, t2, fl / t2 / 1e6), flush=True)
 
 
+def ab():
+    """Per-feature cost on the 1x1 shapes: forward plain / prologue / statistics / both, dgrad plain / mask epilogue,
+    wgrad plain / prologue, and the split-K target (workgroups aimed for)."""
+    shapes = [("l1.conv1", 131072, 256, 64), ("l1.conv3", 131072, 64, 256), ("l2.conv1", 32768, 512, 128),
+              ("l2.conv3", 32768, 128, 512), ("l3.conv1", 8192, 1024, 256), ("l3.conv3", 8192, 256, 1024),
+              ("l4.conv1", 2048, 2048, 512), ("l4.conv3", 2048, 512, 2048), ("sq4096", 4096, 4096, 4096)]
+    print("%-9s | fwd: plain   pro   epi  both | dgrad: plain  mask | wgrad: plain   pro | mi=1: fwd dgrad, mi=2: fwd dgrad | wgrad mi=1 mi=2" % "layer")
+    for name, R, Cin, Cout in shapes:
+        x = torch.randn(R, Cin, device=dev); w = torch.randn(Cout, Cin, device=dev) * 0.1; y = torch.empty(R, Cout, device=dev)
+        dy = torch.randn(R, Cout, device=dev); dx = torch.empty(R, Cin, device=dev); dw = torch.empty(Cout, Cin, device=dev)
+        ss = torch.rand(Cin, 2, device=dev); z = torch.randn(R, Cin, device=dev); v = torch.rand(Cin, device=dev) + 0.5
+        part = torch.empty(lib().scnattn_cgemm_row_tiles(R), 2, max(Cin, Cout), device=dev)
+        ex_p = ConvExtra(pro=1, pro_ss=ss.data_ptr())
+        ex_e = ConvExtra(epi=1, stat_partial=part.data_ptr())
+        ex_b = ConvExtra(pro=1, epi=1, pro_ss=ss.data_ptr(), stat_partial=part.data_ptr())
+        ex_m = ConvExtra(epi=2, stat_partial=part.data_ptr(), ez=z.data_ptr(), emean=v.data_ptr(), einvstd=v.data_ptr(),
+                         egamma=v.data_ptr(), ebeta=v.data_ptr(), ldz=Cin)
+        ex_w = ConvExtra(pro=2, pro_ss=ss.data_ptr())
+        f = [t_us(lambda: cgemm(x, w, False, True, y, R, Cout, Cin, e)) for e in (None, ex_p, ex_e, ex_b)]
+        d = [t_us(lambda: cgemm(dy, w, False, False, dx, R, Cin, Cout, e)) for e in (None, ex_m)]
+        g = [t_us(lambda: cgemm(dy, x, True, False, dw, Cout, Cin, R, e)) for e in (None, ex_w)]
+        tf, tw = [], []
+        for mi in (1, 2):
+            SF.set_option("cgemm_mi", mi)
+            tf.append(t_us(lambda: cgemm(x, w, False, True, y, R, Cout, Cin)))
+            tf.append(t_us(lambda: cgemm(dy, w, False, False, dx, R, Cin, Cout)))
+            tw.append(t_us(lambda: cgemm(dy, x, True, False, dw, Cout, Cin, R)))
+        SF.set_option("cgemm_mi", 0)
+        fmt = lambda l: " ".join("%6.1f" % q for q in l)
+        print("%-9s | %s | %s | %s | %s | %s" % (name, fmt(f), fmt(d), fmt(g), fmt(tf), fmt(tw)), flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("check", "all"):
         check()
     if what in ("time", "all"):
         timeit()
+    if what == "ab":
+        ab()
