@@ -249,8 +249,9 @@ int scnattn_bn_bwd(void* stream, int R, int C, const void* dy, const void* y, co
  *   stat_partial [scnattn_cgemm_row_tiles(R)][2][Cout] (fwd): per 64-row block and output channel, sum(y - s) and
  *       sum((y - s)^2) with s = stat_shift[c] (or 0): the statistics pass of the NEXT BatchNorm, fixed order;
  *   ez / emean / einvstd / egamma / ebeta (dgrad): the result is masked with the ReLU mask recomputed from the
- *       BatchNorm input z ([R][Cin], leading dimension ldz), g = dx * [fma((z-mean)*invstd, gamma, beta) > 0], and
- *       stat_partial receives sum(g), sum(g * xhat): the two reductions of that BatchNorm's backward pass.
+ *       BatchNorm input z ([R][Cin], leading dimension ldz), g = dx * [fma((z-mean)*invstd, gamma, beta) > 0] -- or,
+ *       when pro_ss is given, * [fma(z, scale, shift) > 0], bit for bit the mask of what a forward prologue computed --
+ *       and stat_partial receives sum(g), sum(g * xhat): the two reductions of that BatchNorm's backward pass.
  * stride > 1 (downsample.0): input rows are gathered / scattered at (n, ho*stride, wo*stride) of an Hi x Wi map.
  * ws / ws_floats: split-K partial sums (shapes whose 128x128 tile grid cannot fill the chip); may be NULL. */
 typedef struct scnattn_conv_extra {

@@ -582,11 +582,19 @@ __global__ __launch_bounds__(256) void cstats_kernel(CArgs g) {
     if (c < g.N) {
         f32x4 sft = {0.f, 0.f, 0.f, 0.f}, mu = sft, is = sft, ga = sft, be = sft;
         if (MODE == 1 && g.stat_shift) sft = *reinterpret_cast<const f32x4*>(g.stat_shift + c);
+        bool folded = false;
         if (MODE == 2) {
             mu = *reinterpret_cast<const f32x4*>(g.emean + c);
             is = *reinterpret_cast<const f32x4*>(g.einvstd + c);
-            ga = *reinterpret_cast<const f32x4*>(g.egamma + c);
-            be = *reinterpret_cast<const f32x4*>(g.ebeta + c);
+            if (g.pro_ss) {   // the mask of the function the forward pass actually evaluated: relu(fma(z, scale, shift))
+                folded = true;
+                const f32x4 t0 = *reinterpret_cast<const f32x4*>(g.pro_ss + 2 * c), t1 = *reinterpret_cast<const f32x4*>(g.pro_ss + 2 * c + 4);
+                ga = f32x4{t0[0], t0[2], t1[0], t1[2]};
+                be = f32x4{t0[1], t0[3], t1[1], t1[3]};
+            } else {
+                ga = *reinterpret_cast<const f32x4*>(g.egamma + c);
+                be = *reinterpret_cast<const f32x4*>(g.ebeta + c);
+            }
         }
         const long mn = (long)g.M * g.N;
         f32x4 v[4], zz[4];
@@ -617,7 +625,8 @@ __global__ __launch_bounds__(256) void cstats_kernel(CArgs g) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float xh = (zz[u][k] - mu[k]) * is[k];
-                    if (!(fmaf(xh, ga[k], be[k]) > 0.f)) v[u][k] = 0.f;
+                    const bool on = folded ? (fmaf(zz[u][k], ga[k], be[k]) > 0.f) : (fmaf(xh, ga[k], be[k]) > 0.f);
+                    if (!on) v[u][k] = 0.f;
                     s1[k] += v[u][k];
                     s2[k] = fmaf(v[u][k], xh, s2[k]);
                 }
@@ -713,7 +722,8 @@ int cgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
     const bool gather = ex && ex->stride > 1;
     SCN_ARG(pro == 0 || (pro == 1 && !tA) || (pro == 2 && !tB && tA), "cgemm: prologue / layout mismatch");
     SCN_ARG(epi == 0 || (batch == 1 && beta == 0.f && !bias && !rowmask && ex->stat_partial), "cgemm: statistics epilogue needs a plain product");
-    SCN_ARG(epi != 2 || (ex->ez && ex->emean && ex->einvstd && ex->egamma && ex->ebeta && ex->ldz % 4 == 0), "cgemm: mask epilogue arguments");
+    SCN_ARG(epi != 2 || (ex->ez && ex->emean && ex->einvstd && (ex->pro_ss || (ex->egamma && ex->ebeta)) && ex->ldz % 4 == 0),
+            "cgemm: mask epilogue arguments");
     SCN_ARG(pro == 0 || ex->pro_ss, "cgemm: prologue table");
     SCN_ARG(!gather || (ex->Hi > 0 && ex->Wi > 0 && ex->Ho > 0 && ex->Wo > 0 && batch == 1), "cgemm: gather geometry");
     const bool vec = g_cgemm_vec && N % 4 == 0 && ldc % 4 == 0 && sC % 4 == 0 && aligned16(C) &&

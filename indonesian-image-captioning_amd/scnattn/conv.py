@@ -200,7 +200,8 @@ class _BottleneckFn(torch.autograd.Function):
                                          ws.data_ptr(), ws.numel()), "scnattn_conv1x1_wgrad")
         g2m = torch.empty((Rout, p), **f32)
         ex = ConvExtra(epi=2, stat_partial=part.data_ptr(), ez=z2.data_ptr(), emean=st2[0].data_ptr(),
-                       einvstd=st2[1].data_ptr(), egamma=g2.data_ptr(), ebeta=b2.data_ptr(), ldz=p)
+                       einvstd=st2[1].data_ptr(), egamma=g2.data_ptr(), ebeta=b2.data_ptr(), ldz=p,
+                       pro_ss=ss2.data_ptr())      # mask = [fma(z2, scale, shift) > 0]: what conv3's prologue evaluated
         _chk(h.scnattn_conv1x1_dgrad(st, Rout, p, C4, dz3.data_ptr(), w3.data_ptr(), 0, 0.0, g2m.data_ptr(), C.byref(ex),
                                      ws.data_ptr(), ws.numel()), "scnattn_conv1x1_dgrad")
         dgb2 = torch.empty((2, p), **f32)
