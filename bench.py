@@ -212,6 +212,10 @@ def main():
     ap.add_argument("--attn-depth", type=int, default=1, help="0: shallower load batches in attn_context/dalpha (A/B)")
     ap.add_argument("--gemm-opts", default="", help="diagnostics: target,kmin,kmin_small of the split-K policy")
     ap.add_argument("--graph", action="store_true", help="replay the encoder as HIP graphs (measured slower)")
+    ap.add_argument("--no-fused-conv", action="store_true",
+                    help="A/B: the round-1 trunk (every convolution on MIOpen, BatchNorm as separate passes) instead of "
+                         "the fused Bottleneck on the hand-written 1x1-convolution kernels (scnattn/conv.py)")
+    ap.add_argument("--no-cgemm", action="store_true", help="A/B: dense products on the round-1 sgemm kernel")
     ap.add_argument("--drop-in-call", action="store_true",
                     help="time ONLY the reference's literal call sequence (encoder(imgs) -> decoder(encoder_out, ...), "
                          "trains/attention_scn.py:213-216) as the headline; by default it is timed as a second figure "
@@ -242,6 +246,11 @@ def main():
     from scnattn import _lib
     from scnattn import functional as SF
     from trains.harness import TrainStep, synthetic_batch, DEFAULTS
+    if args.no_fused_conv:
+        from scnattn import conv as _conv
+        _conv.ENABLED = False
+    if args.no_cgemm:
+        SF.set_option("use_cgemm", 0)
     if args.ksplit:
         SF.set_option("ksplit", args.ksplit)
     SF.set_option("chains", args.chains)
