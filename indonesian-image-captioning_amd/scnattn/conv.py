@@ -31,6 +31,7 @@ from . import _lib
 from ._lib import ConvExtra
 
 ENABLED = True          # class-wide switch: tests / A-B runs compare against the unfused path
+SIDE_WGRAD = True       # weight gradients on a second HIP stream (see _Side)
 
 _bufs = {}
 
@@ -43,6 +44,55 @@ def _buffers(dev):
                           torch.empty(2 << 20, device=dev, dtype=torch.float32),      # [64-row blocks][2][C] partials
                           torch.empty(2 << 20, device=dev, dtype=torch.float32))      # BN chunk partials (bn_stats)
     return b
+
+
+class _Side:
+    """Weight gradients off the critical path.  In a block's backward pass the three (four) weight-gradient products
+    feed nothing until the optimizer step, while the d-input chain is strictly serial and every kernel in it has a
+    head (first loads) and a tail (last stores) during which most of the chip idles.  They are enqueued on a second
+    HIP stream, forked from the main stream by an event once their inputs exist, and joined lazily -- `join()` is called
+    by whoever first READS the gradients (FlatBuffer.gather: optimizer step or a data-parallel bucket).  Tensors the
+    side stream touches are tagged with record_stream so the caching allocator keeps them alive."""
+
+    def __init__(self, dev):
+        self.stream = torch.cuda.Stream(device=dev)
+        self.ws = torch.empty(16 << 20, device=dev, dtype=torch.float32)
+        self.pending = None
+
+    def fork(self, main, *tensors):
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self.stream.wait_event(ev)
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self.stream)
+        return self.stream.cuda_stream
+
+    def mark(self):
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        self.pending = ev
+
+    def join(self, main=None):
+        if self.pending is not None:
+            (main or torch.cuda.current_stream(self.stream.device)).wait_event(self.pending)
+            self.pending = None
+
+
+_sides = {}
+
+
+def _side(dev):
+    sd = _sides.get(dev)
+    if sd is None:
+        sd = _sides[dev] = _Side(dev)
+    return sd
+
+
+def join_side_streams():
+    """Make the current stream of every device wait for the weight gradients still running on a side stream."""
+    for sd in _sides.values():
+        sd.join()
 
 
 _fn = None
@@ -192,12 +242,15 @@ class _BottleneckFn(torch.autograd.Function):
                               dgb3[1].data_ptr(), dz3.data_ptr(), None if dres is None else dres.data_ptr()),
              "scnattn_bn_bwd")
         # ---- conv3: wgrad with a2 recomputed on load, dgrad with the bn2 mask / reduction epilogue ----------------
+        main = torch.cuda.current_stream(dev)
+        side = _side(dev) if SIDE_WGRAD else None
         dw3 = None
         if need[8]:
             dw3 = torch.empty_like(w3)
             ex = ConvExtra(pro=2, pro_ss=ss2.data_ptr())
-            _chk(h.scnattn_conv1x1_wgrad(st, Rout, p, C4, dz3.data_ptr(), z2.data_ptr(), dw3.data_ptr(), C.byref(ex),
-                                         ws.data_ptr(), ws.numel()), "scnattn_conv1x1_wgrad")
+            sw, wsw = (side.fork(main, dz3, z2, ss2, dw3), side.ws) if side else (st, ws)
+            _chk(h.scnattn_conv1x1_wgrad(sw, Rout, p, C4, dz3.data_ptr(), z2.data_ptr(), dw3.data_ptr(), C.byref(ex),
+                                         wsw.data_ptr(), wsw.numel()), "scnattn_conv1x1_wgrad")
         g2m = torch.empty((Rout, p), **f32)
         ex = ConvExtra(epi=2, stat_partial=part.data_ptr(), ez=z2.data_ptr(), emean=st2[0].data_ptr(),
                        einvstd=st2[1].data_ptr(), egamma=g2.data_ptr(), ebeta=b2.data_ptr(), ldz=p,
@@ -212,8 +265,18 @@ class _BottleneckFn(torch.autograd.Function):
                                  g2.data_ptr(), dgb2[0].data_ptr(), dgb2[1].data_ptr(), dz2.data_ptr()), "scnattn_bn_bwd_dx")
         del g2m
         # ---- conv2 (MIOpen) -------------------------------------------------------------------------------------
-        da1_4, dw2, _ = torch.ops.aten.convolution_backward(_as4d(dz2, N, Ho, Wo), _as4d(a1, N, Hi, Wi), w2, None, [s, s],
-                                                            [1, 1], [1, 1], False, [0, 0], 1, [True, bool(need[5]), False])
+        dz2_4, a1_4 = _as4d(dz2, N, Ho, Wo), _as4d(a1, N, Hi, Wi)
+        dw2 = None
+        if need[5] and side:
+            side.fork(main, dz2, a1)
+            with torch.cuda.stream(side.stream):
+                _, dw2, _ = torch.ops.aten.convolution_backward(dz2_4, a1_4, w2, None, [s, s], [1, 1], [1, 1], False,
+                                                                [0, 0], 1, [False, True, False])
+            da1_4, _, _ = torch.ops.aten.convolution_backward(dz2_4, a1_4, w2, None, [s, s], [1, 1], [1, 1], False,
+                                                              [0, 0], 1, [True, False, False])
+        else:
+            da1_4, dw2, _ = torch.ops.aten.convolution_backward(dz2_4, a1_4, w2, None, [s, s], [1, 1], [1, 1], False,
+                                                                [0, 0], 1, [True, bool(need[5]), False])
         if not da1_4.is_contiguous(memory_format=torch.channels_last):
             da1_4 = da1_4.contiguous(memory_format=torch.channels_last)
         da1 = _as2d(da1_4)
@@ -227,8 +290,9 @@ class _BottleneckFn(torch.autograd.Function):
         dw1 = None
         if need[2]:
             dw1 = torch.empty_like(w1)
-            _chk(h.scnattn_conv1x1_wgrad(st, Rin, Cin, p, dz1.data_ptr(), x2.data_ptr(), dw1.data_ptr(), None,
-                                         ws.data_ptr(), ws.numel()), "scnattn_conv1x1_wgrad")
+            sw, wsw = (side.fork(main, dz1, x, dw1), side.ws) if side else (st, ws)
+            _chk(h.scnattn_conv1x1_wgrad(sw, Rin, Cin, p, dz1.data_ptr(), x2.data_ptr(), dw1.data_ptr(), None,
+                                         wsw.data_ptr(), wsw.numel()), "scnattn_conv1x1_wgrad")
         # ---- identity branch and d x --------------------------------------------------------------------------------
         dwd = dgbd = None
         dx = None
@@ -241,8 +305,9 @@ class _BottleneckFn(torch.autograd.Function):
             if need[11]:
                 dwd = torch.empty_like(wd)
                 ex = ConvExtra(stride=s, Hi=Hi, Wi=Wi, Ho=Ho, Wo=Wo)
-                _chk(h.scnattn_conv1x1_wgrad(st, Rout, Cin, C4, dzd.data_ptr(), x2.data_ptr(), dwd.data_ptr(),
-                                             C.byref(ex), ws.data_ptr(), ws.numel()), "scnattn_conv1x1_wgrad")
+                sw, wsw = (side.fork(main, dzd, x, dwd), side.ws) if side else (st, ws)
+                _chk(h.scnattn_conv1x1_wgrad(sw, Rout, Cin, C4, dzd.data_ptr(), x2.data_ptr(), dwd.data_ptr(),
+                                             C.byref(ex), wsw.data_ptr(), wsw.numel()), "scnattn_conv1x1_wgrad")
             if need_dx:
                 dx = torch.empty((Rin, Cin), **f32)
                 _chk(h.scnattn_conv1x1_dgrad(st, Rin, Cin, p, dz1.data_ptr(), _wt(h, st, w1, p, Cin).data_ptr(), 1, 0.0,
@@ -257,6 +322,8 @@ class _BottleneckFn(torch.autograd.Function):
             dx = dres
             _chk(h.scnattn_conv1x1_dgrad(st, Rin, Cin, p, dz1.data_ptr(), _wt(h, st, w1, p, Cin).data_ptr(), 1, 1.0,
                                          dx.data_ptr(), None, ws.data_ptr(), ws.numel()), "scnattn_conv1x1_dgrad")
+        if side:
+            side.mark()      # joined by the first reader of the weight gradients (FlatBuffer.gather)
         dx4 = _as4d(dx, N, Hi, Wi) if dx is not None else None
         return (None, dx4, dw1, dgb1[1] if need[3] else None, dgb1[0] if need[4] else None,
                 dw2 if need[5] else None, dgb2[1] if need[6] else None, dgb2[0] if need[7] else None,

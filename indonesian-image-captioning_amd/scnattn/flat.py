@@ -41,6 +41,9 @@ class FlatBuffer:
     def gather(self, indices=None):
         """Copy the gradients autograd produced for parameters `indices` (default: all) into the flat
         buffer and make each ``.grad`` the flat view.  Parameters that received no gradient get zeros."""
+        if self.flat_g.is_cuda:
+            from . import conv as _conv
+            _conv.join_side_streams()     # weight gradients of the fused Bottleneck run on a side stream
         idx = range(len(self.params)) if indices is None else indices
         src, dst = [], []
         for i in idx:
