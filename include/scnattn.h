@@ -283,6 +283,18 @@ int scnattn_conv1x1_dgrad(void* stream, int R, int Cin, int Cout, const float* d
 /* dw [Cout][Cin] = dy^T . f(x) */
 int scnattn_conv1x1_wgrad(void* stream, int R, int Cin, int Cout, const float* dy, const float* x, float* dw,
                           const scnattn_conv_extra* ex, float* ws, long ws_floats);
+/* 3x3 convolutions (padding 1, stride s) of the trunk -- conv2 of every Bottleneck -- as IMPLICIT GEMMs on the same
+ * kernel: no im2col buffer; the nine taps are a walk over K (forward, d input) or a property of the column tile
+ * (d weight); a tap that falls outside the image is a lane whose LDS-DMA offset is out of range, i.e. zeros.
+ * x [N*Hi*Wi][Cin], y / dy [N*Ho*Wo][Cout] channels-last maps, w / dw [Cout][3][3][Cin] (a channels-last conv weight).
+ * Cin, Cout multiples of 16 (d weight: Cin a multiple of 128); d input needs stride 1.
+ * ex may carry epi = 1 (fwd: statistics of y) or epi = 2 (dgrad: ReLU mask from z + BatchNorm-backward sums). */
+int scnattn_conv3x3_fwd(void* stream, int N, int Hi, int Wi, int Cin, int Cout, int stride, const float* x,
+                        const float* w, float* y, const scnattn_conv_extra* ex, float* ws, long ws_floats);
+int scnattn_conv3x3_dgrad(void* stream, int N, int Hi, int Wi, int Cin, int Cout, const float* dy, const float* w,
+                          float* dx, const scnattn_conv_extra* ex, float* ws, long ws_floats);
+int scnattn_conv3x3_wgrad(void* stream, int N, int Hi, int Wi, int Cin, int Cout, int stride, const float* dy,
+                          const float* x, float* dw, float* ws, long ws_floats);
 /* BatchNorm statistics from partial[nchunk][2][C] = {sum(x - s), sum((x - s)^2)} (s = shift[c] or 0), as written by
  * the statistics epilogue above: mean, 1/sqrt(var+eps), running-stat update (momentum; run_* may be NULL), and, when
  * ss_out is given, the folded {scale = gamma*invstd, shift = beta - mean*scale} pairs [C][2] for a consumer's prologue. */

@@ -166,6 +166,36 @@ int scnattn_conv1x1_wgrad(void* stream, int R, int Cin, int Cout, const float* d
                  ws, ws ? ws_floats : 0, ex ? &e : nullptr);
 }
 
+int scnattn_conv3x3_fwd(void* stream, int N, int Hi, int Wi, int Cin, int Cout, int stride, const float* x,
+                        const float* w, float* y, const scnattn_conv_extra* ex, float* ws, long ws_floats) {
+    SCN_ARG(N > 0 && Hi > 0 && Wi > 0 && stride >= 1, "conv3x3_fwd: geometry");
+    ConvExtra e = to_extra(ex);
+    const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
+    e.c3 = 1; e.c3c = Cin; e.c3_src_rows = (long)N * Hi * Wi; e.Hi = Hi; e.Wi = Wi; e.Ho = Ho; e.Wo = Wo; e.stride = stride;
+    return cgemm(ST(stream), false, true, N * Ho * Wo, Cout, 9 * Cin, 1.f, x, Cin, w, 9L * Cin, 0.f, y, Cout, nullptr,
+                 nullptr, 1, 0, 0, 0, ws, ws ? ws_floats : 0, &e);
+}
+
+int scnattn_conv3x3_dgrad(void* stream, int N, int Hi, int Wi, int Cin, int Cout, const float* dy, const float* w,
+                          float* dx, const scnattn_conv_extra* ex, float* ws, long ws_floats) {
+    SCN_ARG(N > 0 && Hi > 0 && Wi > 0, "conv3x3_dgrad: geometry");
+    ConvExtra e = to_extra(ex);
+    // stride 1: dy and dx maps have the same extent; the gathered (source) map is dy
+    e.c3 = 2; e.c3c = Cout; e.c3_src_rows = (long)N * Hi * Wi; e.Hi = Hi; e.Wi = Wi; e.Ho = Hi; e.Wo = Wi; e.stride = 1;
+    return cgemm(ST(stream), false, false, N * Hi * Wi, Cin, 9 * Cout, 1.f, dy, Cout, w, 9L * Cin, 0.f, dx, Cin, nullptr,
+                 nullptr, 1, 0, 0, 0, ws, ws ? ws_floats : 0, &e);
+}
+
+int scnattn_conv3x3_wgrad(void* stream, int N, int Hi, int Wi, int Cin, int Cout, int stride, const float* dy,
+                          const float* x, float* dw, float* ws, long ws_floats) {
+    SCN_ARG(N > 0 && Hi > 0 && Wi > 0 && stride >= 1, "conv3x3_wgrad: geometry");
+    ConvExtra e;
+    const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
+    e.c3 = 3; e.c3c = Cin; e.c3_src_rows = (long)N * Hi * Wi; e.Hi = Hi; e.Wi = Wi; e.Ho = Ho; e.Wo = Wo; e.stride = stride;
+    return cgemm(ST(stream), true, false, Cout, 9 * Cin, N * Ho * Wo, 1.f, dy, Cout, x, Cin, 0.f, dw, 9L * Cin, nullptr,
+                 nullptr, 1, 0, 0, 0, ws, ws ? ws_floats : 0, &e);
+}
+
 int scnattn_bn_finalize(void* stream, long R, int C, int nchunk, const float* partial, const float* shift, float eps,
                         float momentum, float* mean, float* invstd, float* run_mean, float* run_var,
                         const float* gamma, const float* beta, float* ss_out) {

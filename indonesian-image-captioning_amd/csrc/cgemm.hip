@@ -59,7 +59,9 @@ struct CArgs {
     float* ws;
     int mt, nt;                   // tile grid
     // conv extras
-    int gHi, gWi, gHo, gWo, gs;   // row gather (strided 1x1 convolution); gs == 0: none
+    int gHi, gWi, gHo, gWo, gs;   // row gather (strided 1x1 convolution); gs == 0: none.  3x3: source / destination maps
+    int c3c;                      // 3x3 modes: channels per tap of the gathered operand (Cin forward / wgrad, Cout dgrad)
+    long src_rows;                // 3x3 modes: rows of the gathered map (N * gHi * gWi)
     const float* pro_ss;          // interleaved {scale, shift} per channel: PRO 1 per k (A), PRO 2 per n (B)
     float* stat_partial; const float* stat_shift;       // [cdiv(M, 64)][2][N]
     const float* ez; const float* emean; const float* einvstd; const float* egamma; const float* ebeta;  // mask pass
@@ -99,7 +101,12 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // EPI: 0 plain (alpha, beta, bias, rowmask), 1 plain store + column statistics.
 // GATHER: rows of a KC A operand or k-rows of a MC B operand are gathered (strided 1x1 convolution).
 // VEC: the output takes 16-byte row stores.
-template <int MI, bool A_MC, bool B_MC, int PRO, int EPI, bool GATHER, bool VEC>
+// C3: 3x3 convolution (pad 1) as an implicit GEMM -- no im2col buffer, the taps are a walk over K (forward, dgrad) or a
+//     property of the column tile (wgrad), out-of-image taps are lanes whose LDS-DMA offset is out of range (zeros):
+//     1 forward  Y[(n,ho,wo)][co] = sum_{tap,ci} X[(n, ho*s+dh-1, wo*s+dw-1)][ci] * W[co][tap][ci]     (A rows gathered per tap)
+//     2 dgrad    dX[(n,hi,wi)][ci] = sum_{tap,co} dY[(n, hi-dh+1, wi-dw+1)][co] * W[co][tap][ci]       (stride 1; B rows (tap,co))
+//     3 wgrad    dW[co][tap][ci]  = sum_r dY[r][co] * X[(n, ho*s+dh-1, wo*s+dw-1)][ci]                 (B k-rows gathered, tap per n-tile)
+template <int MI, bool A_MC, bool B_MC, int PRO, int EPI, bool GATHER, bool VEC, int C3 = 0>
 __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
     __shared__ __attribute__((aligned(16))) float lds[NSTAGE * STAGE_F];
     constexpr int TM = 64 * MI;
@@ -126,10 +133,13 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
     const int kbeg = sp * g.kper, Kend = min(g.K, kbeg + g.kper);
     const int nk = (Kend - kbeg + TK - 1) / TK;
 
-    const long a_elems = A_MC ? ((long)(g.K - 1) * g.lda + g.M)
-                              : (GATHER ? (gather_row(g, g.M - 1) * g.lda + g.K) : ((long)(g.M - 1) * g.lda + g.K));
-    const long b_elems = B_MC ? ((GATHER && A_MC ? gather_row(g, g.K - 1) : (long)(g.K - 1)) * g.ldb + g.N)
-                              : ((long)(g.N - 1) * g.ldb + g.K);
+    const long a_elems = (C3 == 1 || C3 == 2) ? g.src_rows * g.lda
+                         : A_MC ? ((long)(g.K - 1) * g.lda + g.M)
+                                : (GATHER ? (gather_row(g, g.M - 1) * g.lda + g.K) : ((long)(g.M - 1) * g.lda + g.K));
+    const long b_elems = C3 == 3 ? g.src_rows * g.ldb
+                         : C3 == 2 ? (long)(g.K / 9) * g.ldb
+                         : B_MC ? ((GATHER && A_MC ? gather_row(g, g.K - 1) : (long)(g.K - 1)) * g.ldb + g.N)
+                                : ((long)(g.N - 1) * g.ldb + g.K);
     const __amdgpu_buffer_rsrc_t ars = make_rsrc(A, (unsigned)(a_elems * 4));
     const __amdgpu_buffer_rsrc_t brs = make_rsrc(B, (unsigned)(b_elems * 4));
     const __amdgpu_buffer_rsrc_t srs = make_rsrc(g.pro_ss, PRO == 1 ? (unsigned)g.K * 8u : 0u);
@@ -139,10 +149,21 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
     // MC: chunk = 2 k-rows x 512 B (256 B when the tile is 64 wide: A with MI = 1); lane -> k-row, 4 columns
     unsigned a_off[ACH], b_off[2];   // byte offsets at k = kbeg (KC: + k*4; MC: + k*ld*4 per step)
     bool a_ok[ACH], b_ok[2];
+    int a_nb[ACH], a_h0[ACH], a_w0[ACH];   // 3x3: image base row, top-left tap position of this lane's output pixel
 #pragma unroll
     for (int c = 0; c < ACH; ++c) {
         const int chunk = wave * ACH + c;
-        if (!A_MC) {
+        if (C3 == 1 || C3 == 2) {
+            const int row = chunk * 16 + (lane >> 2), gsrc = (lane & 3) ^ ((row >> 2) & 3);
+            const int grow = m0 + row;
+            a_ok[c] = grow < g.M;
+            const int r = a_ok[c] ? grow : 0, hw = g.gHo * g.gWo;
+            const int n = r / hw, rem = r - n * hw, hd = rem / g.gWo, wd = rem - hd * g.gWo;
+            a_nb[c] = n * g.gHi * g.gWi;
+            a_h0[c] = hd * g.gs - 1;
+            a_w0[c] = wd * g.gs - 1;
+            a_off[c] = (unsigned)(gsrc * 16);
+        } else if (!A_MC) {
             const int row = chunk * 16 + (lane >> 2), gsrc = (lane & 3) ^ ((row >> 2) & 3);
             const int grow = m0 + row;
             a_ok[c] = grow < g.M;
@@ -181,7 +202,14 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
         for (int c = 0; c < ACH; ++c) {
             const int chunk = wave * ACH + c;
             unsigned va;
-            if (!A_MC) {
+            if (C3 == 1 || C3 == 2) {       // k-step -> one tap (c3c % 16 == 0), channels c0 .. c0+15 of it
+                const int tap = k0 / g.c3c, c0 = k0 - tap * g.c3c;
+                int dh = tap / 3, dw = tap - 3 * dh;
+                if (C3 == 2) { dh = 2 - dh; dw = 2 - dw; }
+                const int hi = a_h0[c] + dh, wi = a_w0[c] + dw;
+                const bool ok = a_ok[c] && k0 < Kend && (unsigned)hi < (unsigned)g.gHi && (unsigned)wi < (unsigned)g.gWi;
+                va = ok ? (unsigned)(((long)(a_nb[c] + hi * g.gWi + wi) * g.lda + c0) * 4) + a_off[c] : OOB_OFF;
+            } else if (!A_MC) {
                 const int kk = k0 + 4 * ((lane & 3) ^ (((chunk * 16 + (lane >> 2)) >> 2) & 3));
                 va = (a_ok[c] && kk < Kend) ? a_off[c] + (unsigned)k0 * 4u : OOB_OFF;
             } else {
@@ -199,7 +227,17 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
                 vb = (b_ok[c] && kk < Kend) ? b_off[c] + (unsigned)k0 * 4u : OOB_OFF;
             } else {
                 const int kr = k0 + chunk * 2 + (lane >> 5);
-                if (GATHER && A_MC) {     // wgrad of a strided convolution: k-rows of B = gathered rows of the input map
+                if (C3 == 2) {            // B row k = (tap, co) of W[co][tap][ci]: co*ldb + tap*Cin + ci
+                    const int tap = k0 / g.c3c, co = kr - tap * g.c3c;
+                    vb = (b_ok[c] && kr < Kend) ? (unsigned)(((long)co * g.ldb + (long)tap * g.N + n0 + 4 * (lane & 31)) * 4) : OOB_OFF;
+                } else if (C3 == 3) {     // B k-row r = output pixel; the column tile fixes the tap (c3c % 128 == 0)
+                    const int tap = n0 / g.c3c, ci0 = n0 - tap * g.c3c, dh = tap / 3, dw = tap - 3 * dh;
+                    const int r = kr < Kend ? kr : 0, hw = g.gHo * g.gWo;
+                    const int n = r / hw, rem = r - n * hw, ho = rem / g.gWo, wo = rem - ho * g.gWo;
+                    const int hi = ho * g.gs + dh - 1, wi = wo * g.gs + dw - 1;
+                    const bool ok = b_ok[c] && kr < Kend && (unsigned)hi < (unsigned)g.gHi && (unsigned)wi < (unsigned)g.gWi;
+                    vb = ok ? (unsigned)(((long)(n * g.gHi * g.gWi + hi * g.gWi + wi) * g.ldb + ci0 + 4 * (lane & 31)) * 4) : OOB_OFF;
+                } else if (GATHER && A_MC) {     // wgrad of a strided convolution: k-rows of B = gathered rows of the input map
                     const long src = gather_row(g, kr < Kend ? kr : 0) * g.ldb + n0 + 4 * (lane & 31);
                     vb = (b_ok[c] && kr < Kend) ? (unsigned)(src * 4) : OOB_OFF;
                 } else {
@@ -690,6 +728,20 @@ void launch_ev(hipStream_t st, dim3 grid, const CArgs& g, int kepi, bool vec) {
 }
 
 template <int MI>
+int launch_conv3(hipStream_t st, dim3 grid, const CArgs& g, int c3, int kepi) {
+    dim3 block(256);
+    if (c3 == 1) {
+        if (kepi == 1) hipLaunchKernelGGL((cgemm_kernel<MI, false, false, 0, 1, false, true, 1>), grid, block, 0, st, g);
+        else           hipLaunchKernelGGL((cgemm_kernel<MI, false, false, 0, 0, false, true, 1>), grid, block, 0, st, g);
+    } else if (c3 == 2) {
+        hipLaunchKernelGGL((cgemm_kernel<MI, false, true, 0, 0, false, true, 2>), grid, block, 0, st, g);
+    } else {
+        hipLaunchKernelGGL((cgemm_kernel<MI, true, true, 0, 0, false, true, 3>), grid, block, 0, st, g);
+    }
+    return 0;
+}
+
+template <int MI>
 int launch_layout(hipStream_t st, dim3 grid, const CArgs& g, bool tA, bool tB, int pro, int kepi, bool gather, bool vec) {
     if (!tA && tB) {            // forward of a 1x1 convolution, nn.Linear: both k-contiguous
         if (gather) { if (pro == 1) launch_ev<MI, false, false, 1, true>(st, grid, g, kepi, vec); else launch_ev<MI, false, false, 0, true>(st, grid, g, kepi, vec); }
@@ -719,7 +771,16 @@ int cgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
     SCN_ARG(cgemm_supported(tA, tB, M, N, K, A, lda, B, ldb, sA, sB), "cgemm: operand alignment / size not supported");
     SCN_ARG(beta == 0.f || ((long)(M - 1) * ldc + N) * 4 < 0x7fffffffL, "cgemm: C too large for beta != 0");
     const int pro = ex ? ex->pro : 0, epi = ex ? ex->epi : 0;
-    const bool gather = ex && ex->stride > 1;
+    const int c3 = ex ? ex->c3 : 0;
+    const bool gather = ex && ex->stride > 1 && c3 == 0;
+    if (c3) {
+        SCN_ARG(c3 >= 1 && c3 <= 3 && pro == 0 && batch == 1 && beta == 0.f && !bias && !rowmask, "cgemm: 3x3 mode takes a plain product");
+        SCN_ARG(ex->Hi > 0 && ex->Wi > 0 && ex->Ho > 0 && ex->Wo > 0 && ex->stride >= 1 && ex->c3c > 0 && ex->c3_src_rows > 0, "cgemm: 3x3 geometry");
+        SCN_ARG((c3 == 1 && !tA && tB && K == 9 * ex->c3c && ex->c3c % 16 == 0) ||
+                (c3 == 2 && !tA && !tB && K == 9 * ex->c3c && ex->c3c % 16 == 0 && ex->stride == 1) ||
+                (c3 == 3 && tA && !tB && N == 9 * ex->c3c && ex->c3c % 128 == 0), "cgemm: 3x3 mode / layout / channel multiple");
+        SCN_ARG(ex->c3_src_rows * (c3 == 3 ? ldb : lda) * 4 < 0x7fffffffL, "cgemm: 3x3 source map exceeds the descriptor range");
+    }
     SCN_ARG(pro == 0 || (pro == 1 && !tA) || (pro == 2 && !tB && tA), "cgemm: prologue / layout mismatch");
     SCN_ARG(epi == 0 || (batch == 1 && beta == 0.f && !bias && !rowmask && ex->stat_partial), "cgemm: statistics epilogue needs a plain product");
     SCN_ARG(epi != 2 || (ex->ez && ex->emean && ex->einvstd && (ex->pro_ss || (ex->egamma && ex->ebeta)) && ex->ldz % 4 == 0),
@@ -732,7 +793,7 @@ int cgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
     // row tile: 64 rows when the 128-row grid alone cannot give every CU a workgroup but the 64-row grid can come closer
     const int nt = cdiv(N, TN);
     int mi = 2;
-    if ((long)cdiv(M, 128) * nt * batch < 256 && M > 64) mi = 1;
+    if ((long)cdiv(M, 128) * nt * batch < 256 && M > 64 && c3 != 1 && c3 != 2) mi = 1;
     if (g_cgemm_mi == 1 || g_cgemm_mi == 2) mi = g_cgemm_mi;
     if (ex && ex->force_mi > 0) mi = ex->force_mi;
     const int tmrows = 64 * mi, mt = cdiv(M, tmrows);
@@ -746,6 +807,12 @@ int cgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
         while (S > 1 && (long)S * batch * M * N > ws_floats) --S;
         if (S < 1) S = 1;
     }
+    if ((c3 == 1 || c3 == 2) && ws) {   // deep K (9 taps): 128-row tiles, up to 4 K-slices to reach ~512 workgroups (measured)
+        S = (int)(512 / (tiles > 0 ? tiles : 1));
+        if (S > 4) S = 4;
+        if (S < 1) S = 1;
+        while (S > 1 && (long)S * M * N > ws_floats) --S;
+    }
     if (ex && ex->force_split > 0) {
         S = ex->force_split;
         SCN_ARG(S == 1 || (ws && (long)S * batch * M * N <= ws_floats && S <= CG_MAX_SPLIT), "cgemm: forced split does not fit");
@@ -758,7 +825,8 @@ int cgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = sA; g.sB = sB; g.sC = sC;
     g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta; g.S = S; g.kper = kper; g.ws = ws; g.mt = mt; g.nt = nt;
     if (ex) {
-        g.gHi = ex->Hi; g.gWi = ex->Wi; g.gHo = ex->Ho; g.gWo = ex->Wo; g.gs = gather ? ex->stride : 0;
+        g.gHi = ex->Hi; g.gWi = ex->Wi; g.gHo = ex->Ho; g.gWo = ex->Wo; g.gs = (gather || c3) ? ex->stride : 0;
+        g.c3c = ex->c3c; g.src_rows = ex->c3_src_rows;
         g.pro_ss = ex->pro_ss;
         g.stat_partial = ex->stat_partial; g.stat_shift = ex->stat_shift;
         g.ez = ex->ez; g.emean = ex->emean; g.einvstd = ex->einvstd; g.egamma = ex->egamma; g.ebeta = ex->ebeta; g.ldz = ex->ldz;
@@ -766,8 +834,11 @@ int cgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
     dim3 grid(mt * nt, batch * S), block(256);
     // in-kernel: plain or statistics; the mask pass (epi 2) and every epilogue of a split product run in the second launch
     const int kepi = (S > 1 || epi == 2) ? 0 : epi;
-    if (mi == 2) SCN_TRY(launch_layout<2>(st, grid, g, tA, tB, pro, kepi, gather, vec));
-    else         SCN_TRY(launch_layout<1>(st, grid, g, tA, tB, pro, kepi, gather, vec));
+    if (c3) {
+        SCN_ARG(vec, "cgemm: 3x3 mode needs 16-byte row stores");
+        if (mi == 2) SCN_TRY(launch_conv3<2>(st, grid, g, c3, kepi)); else SCN_TRY(launch_conv3<1>(st, grid, g, c3, kepi));
+    } else if (mi == 2) SCN_TRY(launch_layout<2>(st, grid, g, tA, tB, pro, kepi, gather, vec));
+    else SCN_TRY(launch_layout<1>(st, grid, g, tA, tB, pro, kepi, gather, vec));
     SCN_LAUNCH_CHECK();
     if (S > 1 || epi == 2) {
         if (epi == 0) {

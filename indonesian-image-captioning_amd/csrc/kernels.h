@@ -31,6 +31,9 @@ struct ConvExtra {
     int stride = 1, Hi = 0, Wi = 0, Ho = 0, Wo = 0;   // stride > 1: rows of the activation operand are gathered
     int force_split = 0;      // tests / tuning: > 0 forces the split-K factor
     int force_mi = 0;         // tests / tuning: 1 / 2 forces the 64- / 128-row tile
+    int c3 = 0;               // 3x3 convolution as an implicit GEMM: 1 forward, 2 dgrad (stride 1), 3 wgrad
+    int c3c = 0;              // channels per tap of the gathered operand
+    long c3_src_rows = 0;     // rows of the gathered map
 };
 bool cgemm_supported(bool tA, bool tB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                      long sA, long sB);

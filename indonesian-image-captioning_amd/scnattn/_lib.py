@@ -71,6 +71,9 @@ _SIGS = {
     "scnattn_conv1x1_fwd": ([vp, i32, i32, i32, vp, vp, vp, C.POINTER(ConvExtra), vp, i64], i32),
     "scnattn_conv1x1_dgrad": ([vp, i32, i32, i32, vp, vp, i32, f32, vp, C.POINTER(ConvExtra), vp, i64], i32),
     "scnattn_conv1x1_wgrad": ([vp, i32, i32, i32, vp, vp, vp, C.POINTER(ConvExtra), vp, i64], i32),
+    "scnattn_conv3x3_fwd": ([vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, C.POINTER(ConvExtra), vp, i64], i32),
+    "scnattn_conv3x3_dgrad": ([vp, i32, i32, i32, i32, i32, vp, vp, vp, C.POINTER(ConvExtra), vp, i64], i32),
+    "scnattn_conv3x3_wgrad": ([vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i64], i32),
     "scnattn_bn_finalize": ([vp, i64, i32, i32, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp], i32),
     "scnattn_bn_bwd_finalize": ([vp, i32, i32, vp, vp, vp], i32),
     "scnattn_bn_stats_fold": ([vp, i32, i32, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp], i32),

@@ -32,6 +32,9 @@ from ._lib import ConvExtra
 
 ENABLED = True          # class-wide switch: tests / A-B runs compare against the unfused path
 SIDE_WGRAD = True       # weight gradients on a second HIP stream (see _Side)
+CONV3 = "auto"          # conv2 (3x3) forward / d input: "hip" = the implicit-GEMM mode of csrc/cgemm.hip, "miopen", or
+                        # "auto" = time both once per shape on first use and keep the faster (what MIOpen's own find
+                        # step does among its solvers); the 3x3 weight gradient stays on MIOpen (side stream)
 
 _bufs = {}
 
@@ -44,6 +47,33 @@ def _buffers(dev):
                           torch.empty(2 << 20, device=dev, dtype=torch.float32),      # [64-row blocks][2][C] partials
                           torch.empty(2 << 20, device=dev, dtype=torch.float32))      # BN chunk partials (bn_stats)
     return b
+
+
+_c3_choice = {}
+
+
+def _conv3_use_hip(kind, key, run_hip, run_miopen):
+    """-> True when the hand-written 3x3 path is to be used for this (kind, shape).  "auto": both are timed once
+    (3 launches each after one warm-up, HIP events) the first time a shape is seen."""
+    if CONV3 == "hip":
+        return True
+    if CONV3 == "miopen":
+        return False
+    k = (kind,) + key
+    c = _c3_choice.get(k)
+    if c is None:
+        t = []
+        for fn in (run_hip, run_miopen):
+            fn()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(3):
+                fn()
+            b.record()
+            b.synchronize()
+            t.append(a.elapsed_time(b))
+        c = _c3_choice[k] = t[0] <= t[1] * 1.02
+    return c
 
 
 class _Side:
@@ -178,17 +208,35 @@ class _BottleneckFn(torch.autograd.Function):
         a1 = torch.empty_like(z1)
         _chk(h.scnattn_bn_apply(st, Rin, p, z1.data_ptr(), None, 0, st1[0].data_ptr(), st1[1].data_ptr(), g1.data_ptr(),
                                 b1.data_ptr(), 1, a1.data_ptr()), "scnattn_bn_apply")
-        # conv2 (3x3, MIOpen) + bn2 statistics pass with the folded scale/shift
-        z2_4 = torch.ops.aten.convolution(_as4d(a1, N, Hi, Wi), w2, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1)
-        if not z2_4.is_contiguous(memory_format=torch.channels_last):
-            z2_4 = z2_4.contiguous(memory_format=torch.channels_last)
-        z2 = _as2d(z2_4)
-        st2 = torch.empty((2, p), device=dev, dtype=torch.float32)
-        ss2 = torch.empty((p, 2), device=dev, dtype=torch.float32)
-        _chk(h.scnattn_bn_stats_fold(st, Rout, p, z2.data_ptr(), bn2.eps, bn2.momentum, bnpart.data_ptr(),
-                                     st2[0].data_ptr(), st2[1].data_ptr(), bn2.running_mean.data_ptr(),
-                                     bn2.running_var.data_ptr(), g2.data_ptr(), b2.data_ptr(), ss2.data_ptr()),
-             "scnattn_bn_stats_fold")
+        # conv2 (3x3): the implicit-GEMM mode of the same kernel with the bn2 statistics epilogue, or MIOpen + a statistics
+        # pass -- whichever is faster for this shape (CONV3)
+        a1_4 = _as4d(a1, N, Hi, Wi)
+        c3ok = p % 16 == 0 and w2.is_contiguous(memory_format=torch.channels_last)
+
+        def hip_fwd():
+            z = torch.empty((Rout, p), device=dev, dtype=torch.float32)
+            ex3 = ConvExtra(epi=1, stat_partial=part.data_ptr(), stat_shift=bn2.running_mean.data_ptr())
+            _chk(h.scnattn_conv3x3_fwd(st, N, Hi, Wi, p, p, s, a1.data_ptr(), w2.data_ptr(), z.data_ptr(), C.byref(ex3),
+                                       ws.data_ptr(), ws.numel()), "scnattn_conv3x3_fwd")
+            return z
+
+        def miopen_fwd():
+            z4 = torch.ops.aten.convolution(a1_4, w2, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1)
+            if not z4.is_contiguous(memory_format=torch.channels_last):
+                z4 = z4.contiguous(memory_format=torch.channels_last)
+            return _as2d(z4)
+
+        if c3ok and _conv3_use_hip("fwd", (N, Hi, Wi, p, s), hip_fwd, miopen_fwd):
+            z2 = hip_fwd()
+            st2, ss2 = _finalize(h, st, Rout, p, part, bn2, True, g2, b2, True)
+        else:
+            z2 = miopen_fwd()
+            st2 = torch.empty((2, p), device=dev, dtype=torch.float32)
+            ss2 = torch.empty((p, 2), device=dev, dtype=torch.float32)
+            _chk(h.scnattn_bn_stats_fold(st, Rout, p, z2.data_ptr(), bn2.eps, bn2.momentum, bnpart.data_ptr(),
+                                         st2[0].data_ptr(), st2[1].data_ptr(), bn2.running_mean.data_ptr(),
+                                         bn2.running_var.data_ptr(), g2.data_ptr(), b2.data_ptr(), ss2.data_ptr()),
+                 "scnattn_bn_stats_fold")
         # conv3 with the bn2+relu prologue (+ bn3 statistics)
         ex = ConvExtra(pro=1, epi=1, pro_ss=ss2.data_ptr(), stat_partial=part.data_ptr(),
                        stat_shift=bn3.running_mean.data_ptr())
@@ -272,8 +320,20 @@ class _BottleneckFn(torch.autograd.Function):
             with torch.cuda.stream(side.stream):
                 _, dw2, _ = torch.ops.aten.convolution_backward(dz2_4, a1_4, w2, None, [s, s], [1, 1], [1, 1], False,
                                                                 [0, 0], 1, [False, True, False])
-            da1_4, _, _ = torch.ops.aten.convolution_backward(dz2_4, a1_4, w2, None, [s, s], [1, 1], [1, 1], False,
-                                                              [0, 0], 1, [True, False, False])
+            c3ok = s == 1 and p % 16 == 0 and w2.is_contiguous(memory_format=torch.channels_last)
+
+            def hip_dgrad():
+                d = torch.empty((Rin, p), **f32)
+                _chk(h.scnattn_conv3x3_dgrad(st, N, Hi, Wi, p, p, dz2.data_ptr(), w2.data_ptr(), d.data_ptr(), None,
+                                             ws.data_ptr(), ws.numel()), "scnattn_conv3x3_dgrad")
+                return _as4d(d, N, Hi, Wi)
+
+            def miopen_dgrad():
+                return torch.ops.aten.convolution_backward(dz2_4, a1_4, w2, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1,
+                                                           [True, False, False])[0]
+
+            da1_4 = hip_dgrad() if (c3ok and _conv3_use_hip("dgrad", (N, Hi, Wi, p), hip_dgrad, miopen_dgrad)) \
+                else miopen_dgrad()
         else:
             da1_4, dw2, _ = torch.ops.aten.convolution_backward(dz2_4, a1_4, w2, None, [s, s], [1, 1], [1, 1], False,
                                                                 [0, 0], 1, [True, bool(need[5]), False])

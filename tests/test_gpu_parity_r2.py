@@ -481,11 +481,13 @@ _BLOCKS = [  # (name, inplanes, planes, stride, H) -- every distinct 1x1-convolu
     ("layer3.0", 512, 256, 2, 32), ("layer3.1", 1024, 256, 1, 16), ("layer4.0", 1024, 512, 2, 16), ("layer4.1", 2048, 512, 1, 8)]
 
 
+@pytest.mark.parametrize("conv3", ["hip", "miopen"])
 @pytest.mark.parametrize("small", [True, False])
 @pytest.mark.parametrize("name,inplanes,planes,stride,H", _BLOCKS)
-def test_fused_bottleneck_vs_fp64(dev, name, inplanes, planes, stride, H, small):
+def test_fused_bottleneck_vs_fp64(dev, name, inplanes, planes, stride, H, small, conv3):
     """One Bottleneck of the trunk behind models/encoders/caption.py:17-22 through scnattn/conv.py -- conv1 / conv3 /
-    downsample.0 forward, d input and d weight on csrc/cgemm.hip with the BatchNorm statistics epilogue, the
+    downsample.0 forward, d input and d weight (and, with conv3 = "hip", the 3x3 conv2 forward and stride-1 d input as
+    implicit GEMMs) on csrc/cgemm.hip with the BatchNorm statistics epilogue, the
     normalise-on-load prologue, the mask + reduction epilogue and the in-place residual-gradient accumulation --
     against the SAME module in fp64 on the CPU (plain torch conv / batch_norm / relu): output, d x, every parameter
     gradient, running statistics.  Also against the unfused GPU path (MIOpen convolutions + round-1 BN kernels).
@@ -523,12 +525,15 @@ def test_fused_bottleneck_vs_fp64(dev, name, inplanes, planes, stride, H, small)
         g = copy.deepcopy(m).to(dev).to(memory_format=torch.channels_last).train()
         xg = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
         SC.ENABLED = fused
+        SC.CONV3 = conv3        # conv2: the implicit-GEMM 3x3 mode of csrc/cgemm.hip (forward + stride-1 d input) or MIOpen
         try:
             assert SC.usable(g, xg) == fused
             y = g(xg)
             (y * wgt.float().to(dev)).sum().backward()
+            torch.cuda.synchronize()
         finally:
             SC.ENABLED = True
+            SC.CONV3 = "auto"
         res[fused] = (y.detach(), xg.grad.detach(), {k: p.grad.detach() for k, p in g.named_parameters()},
                       {k: b.detach().clone() for k, b in g.named_buffers()})
     rep = []
@@ -579,3 +584,4 @@ def test_cgemm_variants_vs_fp64(dev):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     mod.check()
+    mod.check3()      # the 3x3 implicit-GEMM modes (forward, d input, d weight) against fp64 torch conv2d

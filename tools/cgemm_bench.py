@@ -173,6 +173,60 @@ def timeit():
               % (M, N, K, ta, tb, t0, fl / t0 / 1e6, t1, fl / t1 / 1e6, t2, fl / t2 / 1e6), flush=True)
 
 
+def conv3(x4, w4, stride):
+    """x4 (N,Cin,H,W) channels-last, w4 (Cout,Cin,3,3) channels-last -> y [N*Ho*Wo, Cout] via scnattn_conv3x3_fwd"""
+    N, Cin, H, W = x4.shape
+    Cout = w4.shape[0]
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.empty(N * Ho * Wo, Cout, device=dev)
+    call("scnattn_conv3x3_fwd", stream_of(x4), N, H, W, Cin, Cout, stride, ptr(x4), ptr(w4), ptr(y), None, ptr(WS), WS.numel())
+    return y
+
+
+def check3():
+    g = torch.Generator(device="cpu").manual_seed(1)
+    for (N, H, Cin, Cout, s) in [(2, 8, 128, 128, 1), (3, 10, 128, 256, 2), (2, 7, 256, 128, 1), (2, 16, 128, 128, 2), (1, 5, 512, 512, 1)]:
+        x = torch.randn(N, Cin, H, H, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        w = (0.1 * torch.randn(Cout, Cin, 3, 3, generator=g)).to(dev).contiguous(memory_format=torch.channels_last)
+        Ho = (H - 1) // s + 1
+        ref = F.conv2d(x.double(), w.double(), stride=s, padding=1)
+        y = conv3(x, w, s)
+        e = rel(y, ref.permute(0, 2, 3, 1).reshape(-1, Cout)); assert e < 3e-6, ("conv3 fwd", N, H, Cin, Cout, s, e)
+        dy = torch.randn(N, Cout, Ho, Ho, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        gi, gw = torch.autograd.grad(F.conv2d(x.double().requires_grad_(True), w.double().requires_grad_(True), stride=s, padding=1),
+                                     [], dy.double(), allow_unused=True) if False else (None, None)
+        xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+        F.conv2d(xd, wd, stride=s, padding=1).backward(dy.double())
+        dw = torch.empty_like(w)
+        call("scnattn_conv3x3_wgrad", stream_of(x), N, H, H, Cin, Cout, s, ptr(dy), ptr(x), ptr(dw), ptr(WS), WS.numel())
+        e = rel(dw, wd.grad); assert e < 1e-5, ("conv3 wgrad", N, H, Cin, Cout, s, e)
+        if s == 1:
+            dx = torch.empty_like(x)
+            call("scnattn_conv3x3_dgrad", stream_of(x), N, H, H, Cin, Cout, ptr(dy), ptr(w), ptr(dx), None, ptr(WS), WS.numel())
+            e = rel(dx, xd.grad); assert e < 3e-6, ("conv3 dgrad", N, H, Cin, Cout, e)
+    print("check3 ok", flush=True)
+
+
+def time3():
+    print("3x3: layer (N,H,Cin,Cout,s) | fwd new / miopen (TF new) | dgrad new / miopen | wgrad new / miopen")
+    for name, H, Cin, s in [("l1", 64, 64, 1), ("l2.0", 64, 128, 2), ("l2", 32, 128, 1), ("l3.0", 32, 256, 2), ("l3", 16, 256, 1),
+                            ("l4.0", 16, 512, 2), ("l4", 8, 512, 1)]:
+        N, Cout = 32, Cin
+        x = torch.randn(N, Cin, H, H, device=dev).contiguous(memory_format=torch.channels_last)
+        w = (0.1 * torch.randn(Cout, Cin, 3, 3, device=dev)).contiguous(memory_format=torch.channels_last)
+        Ho = (H - 1) // s + 1
+        dy = torch.randn(N, Cout, Ho, Ho, device=dev).contiguous(memory_format=torch.channels_last)
+        y = torch.empty(N * Ho * Ho, Cout, device=dev); dx = torch.empty_like(x); dw = torch.empty_like(w)
+        f0 = t_us(lambda: call("scnattn_conv3x3_fwd", stream_of(x), N, H, H, Cin, Cout, s, ptr(x), ptr(w), ptr(y), None, ptr(WS), WS.numel()))
+        f1 = t_us(lambda: F.conv2d(x, w, stride=s, padding=1))
+        g0 = t_us(lambda: call("scnattn_conv3x3_dgrad", stream_of(x), N, H, H, Cin, Cout, ptr(dy), ptr(w), ptr(dx), None, ptr(WS), WS.numel())) if s == 1 else float("nan")
+        g1 = t_us(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False]))
+        h0 = t_us(lambda: call("scnattn_conv3x3_wgrad", stream_of(x), N, H, H, Cin, Cout, s, ptr(dy), ptr(x), ptr(dw), ptr(WS), WS.numel())) if Cin % 128 == 0 else float("nan")
+        h1 = t_us(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False]))
+        fl = 2.0 * N * Ho * Ho * Cout * 9 * Cin
+        print("%-5s (%d,%d,%d,%d,%d) | %7.1f / %7.1f (%5.1f TF) | %7.1f / %7.1f | %7.1f / %7.1f" % (name, N, H, Cin, Cout, s, f0, f1, fl / f0 / 1e6, g0, g1, h0, h1), flush=True)
+
+
 def ab():
     """Per-feature cost on the 1x1 shapes: forward plain / prologue / statistics / both, dgrad plain / mask epilogue,
     wgrad plain / prologue, and the split-K target (workgroups aimed for)."""
@@ -213,3 +267,7 @@ if __name__ == "__main__":
         timeit()
     if what == "ab":
         ab()
+    if what in ("check3", "all3"):
+        check3()
+    if what in ("time3", "all3"):
+        time3()
