@@ -387,6 +387,11 @@ def main():
                        "harness: encoder(imgs, pooled=False) -> decoder(None, ..., prepool=trunk map)"},
             "rccl_world_size": dist.get_world_size() if dist_on else 1,
         }
+        if not args.decoder_only and not args.no_fused_conv:
+            from scnattn import conv as _conv
+            out["config"]["trunk"] = ("fused Bottleneck: every 1x1 convolution (fwd, dgrad, wgrad) on csrc/cgemm.hip with "
+                                      "BatchNorm prologues/epilogues; 3x3 fwd/dgrad per shape by autotune (SCNATTN_CONV3=%s): "
+                                      % _conv.CONV3) + ", ".join("%s%s=%s" % (k[0], list(k[1:]), v) for k, v in sorted(_conv.conv3_choices().items()))
         if elapsed_di is not None:
             out["drop_in_call"] = {"value": round(world * args.batch * args.steps / elapsed_di, 3), "unit": "images/sec",
                                    "ms_per_step": round(1e3 * elapsed_di / args.steps, 3),

@@ -24,6 +24,7 @@ The strided 1x1 downsample convolution gathers its input rows inside the kernel.
 `Bottleneck.forward` (scnattn/resnet.py) calls `bottleneck()` for fp32 CUDA inputs in training mode; everything else
 (eval mode, bf16 autocast, CPU structure tests) takes the unfused module path."""
 import ctypes as C
+import os
 
 import torch
 
@@ -32,7 +33,7 @@ from ._lib import ConvExtra
 
 ENABLED = True          # class-wide switch: tests / A-B runs compare against the unfused path
 SIDE_WGRAD = True       # weight gradients on a second HIP stream (see _Side)
-CONV3 = "auto"          # conv2 (3x3) forward / d input: "hip" = the implicit-GEMM mode of csrc/cgemm.hip, "miopen", or
+CONV3 = os.environ.get("SCNATTN_CONV3", "auto")   # conv2 (3x3) forward / d input: "hip" = the implicit-GEMM mode of csrc/cgemm.hip, "miopen", or
                         # "auto" = time both once per shape on first use and keep the faster (what MIOpen's own find
                         # step does among its solvers); the 3x3 weight gradient stays on MIOpen (side stream)
 
@@ -74,6 +75,11 @@ def _conv3_use_hip(kind, key, run_hip, run_miopen):
             t.append(a.elapsed_time(b))
         c = _c3_choice[k] = t[0] <= t[1] * 1.02
     return c
+
+
+def conv3_choices():
+    """{(kind, N, H, W, C[, stride]): "hip" | "miopen"} as decided so far by the per-shape autotune."""
+    return {k: ("hip" if v else "miopen") for k, v in _c3_choice.items()}
 
 
 class _Side:
