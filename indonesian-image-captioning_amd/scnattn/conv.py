@@ -77,6 +77,9 @@ def _conv3_use_hip(kind, key, run_hip, run_miopen):
     return c
 
 
+CONV3_WGRAD = os.environ.get("SCNATTN_CONV3_WGRAD", "miopen")   # 3x3 weight gradient: "miopen" (on the side stream; measured 793 vs 771 images/s) or the implicit-GEMM mode ("hip")
+
+
 def conv3_choices():
     """{(kind, N, H, W, C[, stride]): "hip" | "miopen"} as decided so far by the per-shape autotune."""
     return {k: ("hip" if v else "miopen") for k, v in _c3_choice.items()}
@@ -322,10 +325,16 @@ class _BottleneckFn(torch.autograd.Function):
         dz2_4, a1_4 = _as4d(dz2, N, Ho, Wo), _as4d(a1, N, Hi, Wi)
         dw2 = None
         if need[5] and side:
-            side.fork(main, dz2, a1)
-            with torch.cuda.stream(side.stream):
-                _, dw2, _ = torch.ops.aten.convolution_backward(dz2_4, a1_4, w2, None, [s, s], [1, 1], [1, 1], False,
-                                                                [0, 0], 1, [False, True, False])
+            if CONV3_WGRAD == "hip" and p % 128 == 0 and w2.is_contiguous(memory_format=torch.channels_last):
+                dw2 = torch.empty_like(w2)
+                sw = side.fork(main, dz2, a1, dw2)
+                _chk(h.scnattn_conv3x3_wgrad(sw, N, Hi, Wi, p, p, s, dz2.data_ptr(), a1.data_ptr(), dw2.data_ptr(),
+                                             side.ws.data_ptr(), side.ws.numel()), "scnattn_conv3x3_wgrad")
+            else:
+                side.fork(main, dz2, a1)
+                with torch.cuda.stream(side.stream):
+                    _, dw2, _ = torch.ops.aten.convolution_backward(dz2_4, a1_4, w2, None, [s, s], [1, 1], [1, 1], False,
+                                                                    [0, 0], 1, [False, True, False])
             c3ok = s == 1 and p % 16 == 0 and w2.is_contiguous(memory_format=torch.channels_last)
 
             def hip_dgrad():
