@@ -32,7 +32,10 @@ const char* scnattn_last_error(void);
  * "chains" (1, default; 2: the recurrence is enqueued as two independent half-batch dependency chains,
  * chain 0 on the caller's stream and chain 1 on a library-owned side stream by a helper thread,
  * forked and joined with events so the call stays ordered on the caller's stream; bit-identical, slower),
- * "fuse_attn" (1: scores+softmax+context in one launch; slower, default 0).
+ * "fuse_attn" (1: scores+softmax+context in one launch; slower, default 0),
+ * "attn_handoff" (1, default: on the pooled path the attention scores and the context run as ONE launch whose E-chunk
+ * workgroups share the scores of a batch row through an in-launch hand-off; 0: two launches),
+ * "handoff_check" (1: scnattn_seq_fwd synchronises at its end and returns an error if a hand-off wait timed out).
  * Returns -1 for an unknown name or value. */
 int scnattn_set_option(const char* name, int value);
 /* Sums since the last call: out6 = {forward loop ms, forward steps, backward loop ms, backward steps,

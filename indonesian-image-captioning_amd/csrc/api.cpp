@@ -24,6 +24,7 @@ extern int g_profile;
 extern int g_fuse_attn;
 extern int g_chains;
 extern int g_attn_depth;
+extern int g_attn_handoff, g_handoff_check;
 extern int g_gemm_target, g_gemm_kmin, g_gemm_kmin_small, g_gemm_gate, g_use_cgemm, g_cgemm_target, g_cgemm_kmin, g_cgemm_vec, g_cgemm_mi;
 int profile_collect(double* out);
 int seq_workspace(const scnattn_dims* d, const scnattn_pool* pool, size_t* saved_bytes, size_t* scratch_bytes);
@@ -60,6 +61,8 @@ int scnattn_set_option(const char* name, int value) {
         return 0;
     }
     if (name && std::strcmp(name, "attn_depth") == 0) { g_attn_depth = value != 0; return 0; }
+    if (name && std::strcmp(name, "attn_handoff") == 0) { g_attn_handoff = value != 0; return 0; }
+    if (name && std::strcmp(name, "handoff_check") == 0) { g_handoff_check = value != 0; return 0; }
     if (name && std::strcmp(name, "gemm_target") == 0 && value >= 1) { g_gemm_target = value; return 0; }
     if (name && std::strcmp(name, "gemm_gate") == 0 && value >= 1) { g_gemm_gate = value; return 0; }
     if (name && std::strcmp(name, "gemm_kmin") == 0 && value >= 16) { g_gemm_kmin = value; return 0; }

@@ -29,6 +29,8 @@ int g_chains = 1;        // 2: the recurrence runs as two independent half-batch
                          //    half-batch launch takes as long as a full one (attn_context 15.1 vs 14.1 us)
 int g_fuse_attn = 0;     // 1: scores+softmax+context+gate as one launch (measured SLOWER: 54.0 vs 47.5 us/step,
                          //    each E-chunk workgroup recomputes all 196 scores through its CU's L2 port)
+extern int g_attn_handoff;   // 1 (default): pooled path runs scores + context as one launch with an in-launch hand-off
+int g_handoff_check = 0;     // 1: seq_fwd synchronises at its end and reports a hand-off time-out (tests)
 
 // ---- optional in-stream timing of the recurrence loops (bench.py's roofline figure) ------------------
 struct LoopEvent { hipEvent_t a, b; int kind, steps; };
@@ -93,7 +95,7 @@ struct Saved {
 constexpr long GEMM_WS_FLOATS = 8L << 20;   // 32 MiB of split-K partials for the big GEMMs
 
 struct FwdScratch {
-    float *WcatA, *WD, *slabA, *e, *slabC, *xcat, *slabD, *gws, *y;
+    float *WcatA, *WD, *slabA, *e, *slabC, *xcat, *slabD, *gws, *y, *cnt;
 };
 
 struct BwdScratch {
@@ -145,6 +147,7 @@ size_t carve_fwd(const scnattn_dims& d, int Q, float* base, FwdScratch& s) {
     s.slabD = c.take(sz(SCN_MAX_KSPLIT, 4, B, D));
     s.gws = c.take(GEMM_WS_FLOATS);
     s.y = (d.has_att && Q > 0) ? c.take(sz(B, Q, d.A)) : nullptr;
+    s.cnt = (d.has_att && Q > 0) ? c.take(sz(B + 1)) : nullptr;    // hand-off counters [B] + time-out flag [1] (ints)
     return c.off * sizeof(float);
 }
 
@@ -363,6 +366,8 @@ int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
 
     // ---- the recurrence --------------------------------------------------------------------------
     const long BD = (long)B * D;
+    const bool handoff = d.has_att && Q > 0 && attn_handoff_ok(B, P, E, A, enc, s.att1, pd);
+    if (handoff) SCN_HIP(hipMemsetAsync(f.cnt, 0, sizeof(int) * (B + 1), st));
     hipEvent_t ev0 = prof_begin(st);
     SCN_TRY(run_chains(st, 0, B, [&](hipStream_t cs, int r0, int rmax) -> int {
         const float* enc_c = enc + (long)r0 * (Q > 0 ? Q : P) * E;
@@ -385,7 +390,17 @@ int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
             Slabs pz{nullptr, 0, 0, 0};
             if (d.has_att) {
                 float* alpha_out = alphas + (long)r0 * T * P + (long)t * P;
-                if (Q > 0) {
+                if (handoff) {
+                    hipEvent_t evc = g_profile >= 2 ? prof_begin(cs) : nullptr;
+                    int* cnt = reinterpret_cast<int*>(f.cnt);
+                    SCN_TRY(attn_handoff(cs, bt_, P, E, A, t, enc_c, att1_c, pd, Slabs{slabA, ksA, (long)B * NA, NA},
+                                         w->attention_decoder_att_bias, w->attention_full_att_weight,
+                                         w->attention_full_att_bias, Slabs{slabA + A, ksA, (long)B * NA, NA},
+                                         w->f_beta_bias, e_c, cnt + r0, cnt + B, alpha_out, (long)T * P,
+                                         s.alpha_tm + rowT * P, s.alphaq_tm + rowT * Q, s.att2_all + rowT * A,
+                                         s.awe_all + rowT * E, s.gate_all + rowT * E, s.z_all + rowT * E));
+                    prof_end(cs, evc, 2, 1);
+                } else if (Q > 0) {
                     SCN_TRY(attn_scores(cs, bt_, P, A, att1_c, Slabs{slabA, ksA, (long)B * NA, NA},
                                         w->attention_decoder_att_bias, w->attention_full_att_weight,
                                         w->attention_full_att_bias, e_c, s.att2_all + rowT * A));
@@ -437,6 +452,12 @@ int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
     SCN_TRY(hidden_to_bm(st, B, T, D, dl_dev, s.Hs + BD, drop_mask, s.Hd_bm, s.rowmask));
     SCN_TRY(sgemm_ws(st, false, true, B * T, d.V, D, 1.f, s.Hd_bm, D, w->fc_weight, D, 0.f, preds, d.V, w->fc_bias,
                   s.rowmask, 1, 0, 0, 0, f.gws, GEMM_WS_FLOATS));
+    if (handoff && g_handoff_check) {
+        int flag = 0;
+        SCN_HIP(hipMemcpyAsync(&flag, reinterpret_cast<int*>(f.cnt) + B, sizeof(int), hipMemcpyDeviceToHost, st));
+        SCN_HIP(hipStreamSynchronize(st));
+        SCN_ARG(flag == 0, "attention hand-off timed out (a chunk workgroup of a batch row never arrived)");
+    }
     return 0;
 }
 

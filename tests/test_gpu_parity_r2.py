@@ -585,3 +585,44 @@ def test_cgemm_variants_vs_fp64(dev):
     spec.loader.exec_module(mod)
     mod.check()
     mod.check3()      # the 3x3 implicit-GEMM modes (forward, d input, d weight) against fp64 torch conv2d
+
+
+@pytest.mark.parametrize("B,ragged", [(32, False), (32, True), (40, True), (3, True)])
+def test_attention_handoff_launch_is_bit_identical_to_two_launches(dev, B, ragged):
+    """Pooled sequence path: scores + softmax + context + gate as ONE launch whose E-chunk workgroups hand the scores
+    of a batch row to each other (csrc/attention.hip::attn_handoff_kernel; sc1 stores -> drained -> counter, bounded
+    poll, sc1 loads, + acquire fence when more than one workgroup per CU can be resident: B = 40) against the
+    attn_scores + attn_context_pooled pair: same arithmetic in the same order, so predictions, alphas and every gradient
+    must be BIT-identical, over a ragged batch (the per-row counters advance only while a row is decoded) and with the
+    time-out flag checked (option handoff_check)."""
+    from models.decoders.attention_scn import AttentionSCN
+    from scnattn import functional as SF
+    torch.manual_seed(3)
+    V, L = 300, 12
+    m = AttentionSCN(512, 128, 512, 128, 100, V, dropout=0.0).to(dev).train()
+    g = torch.Generator().manual_seed(B)
+    x = torch.rand(B, 8, 8, 2048, generator=g).to(dev)
+    tags = torch.rand(B, 100, generator=g).to(dev)
+    lens = torch.randint(3, L + 1, (B,), generator=g) if ragged else torch.full((B,), L)
+    caps = _synthetic_caps(B, V, L, lens, g).to(dev)
+    caplens = lens.unsqueeze(1).to(dev)
+    res = []
+    try:
+        SF.set_option("handoff_check", 1)
+        for mode in (1, 0):
+            SF.set_option("attn_handoff", mode)
+            m.zero_grad(set_to_none=True)
+            xx = x.clone().requires_grad_(True)
+            out = m(None, tags, caps, caplens, prepool=xx, pool_size=14)
+            (out[0].square().sum() + (out[3] ** 2).sum()).backward()
+            torch.cuda.synchronize()
+            res.append((out[0].detach().clone(), out[3].detach().clone(), xx.grad.clone(),
+                        {k: p.grad.clone() for k, p in m.named_parameters()}))
+    finally:
+        SF.set_option("attn_handoff", 1)
+        SF.set_option("handoff_check", 0)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert torch.equal(res[0][2], res[1][2])
+    for k in res[0][3]:
+        assert torch.equal(res[0][3][k], res[1][3][k]), k
+    assert abs(res[0][1][0, 0].sum().item() - 1.0) < 1e-5
