@@ -216,13 +216,17 @@ def main():
                     help="A/B: the round-1 trunk (every convolution on MIOpen, BatchNorm as separate passes) instead of "
                          "the fused Bottleneck on the hand-written 1x1-convolution kernels (scnattn/conv.py)")
     ap.add_argument("--no-cgemm", action="store_true", help="A/B: dense products on the round-1 sgemm kernel")
-    ap.add_argument("--attn-handoff", type=int, default=1,
+    ap.add_argument("--dp-backend", default=os.environ.get("SCNATTN_DP_BACKEND", "torch"), choices=["torch", "cabi"],
+                    help="gradient all-reduce through torch.distributed (RCCL) or through the library's own RCCL "
+                         "communicator (include/scnattn.h scnattn_dp_comm_*)")
+    ap.add_argument("--attn-handoff", type=int, default=0,
                     help="0: attention scores and context as two launches (A/B of the in-launch hand-off)")
     ap.add_argument("--drop-in-call", action="store_true",
                     help="time ONLY the reference's literal call sequence (encoder(imgs) -> decoder(encoder_out, ...), "
                          "trains/attention_scn.py:213-216) as the headline; by default it is timed as a second figure "
                          "(`drop_in_call` in the JSON line) after the harness sequence")
     args = ap.parse_args()
+    os.environ["SCNATTN_DP_BACKEND"] = args.dp_backend
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))       # before any GPU call
@@ -389,6 +393,7 @@ def main():
                        "call_sequence": "drop-in: encoder(imgs) -> decoder(encoder_out, ...)" if args.drop_in_call else
                        "harness: encoder(imgs, pooled=False) -> decoder(None, ..., prepool=trunk map)"},
             "rccl_world_size": dist.get_world_size() if dist_on else 1,
+            "dp_backend": (args.dp_backend if dist_on else None),
         }
         if not args.decoder_only and not args.no_fused_conv:
             from scnattn import conv as _conv

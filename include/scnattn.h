@@ -33,8 +33,8 @@ const char* scnattn_last_error(void);
  * chain 0 on the caller's stream and chain 1 on a library-owned side stream by a helper thread,
  * forked and joined with events so the call stays ordered on the caller's stream; bit-identical, slower),
  * "fuse_attn" (1: scores+softmax+context in one launch; slower, default 0),
- * "attn_handoff" (1, default: on the pooled path the attention scores and the context run as ONE launch whose E-chunk
- * workgroups share the scores of a batch row through an in-launch hand-off; 0: two launches),
+ * "attn_handoff" (1: on the pooled path the attention scores and the context run as ONE launch whose E-chunk
+ * workgroups share the scores of a batch row through an in-launch hand-off; default 0 = two launches: measured equal),
  * "handoff_check" (1: scnattn_seq_fwd synchronises at its end and returns an error if a hand-off wait timed out).
  * Returns -1 for an unknown name or value. */
 int scnattn_set_option(const char* name, int value);
@@ -314,6 +314,25 @@ int scnattn_bn_bwd_dx(void* stream, int R, int C, const float* g, const float* z
                       const float* gamma, const float* dbeta, const float* dgamma, float* dz);
 /* dbeta[c] = sum_chunks partial[.][0][c], dgamma[c] = sum_chunks partial[.][1][c] (the mask epilogue's sums) */
 int scnattn_bn_bwd_finalize(void* stream, int C, int nchunk, const float* partial, float* dbeta, float* dgamma);
+
+/* ---- data-parallel gradient exchange (the reference has no distributed code) ---------------------
+ * One process per GPU.  RCCL SUM all-reduce of gradient buckets on a library-owned communication stream, ordered
+ * against the caller's compute stream by HIP events, so a bucket's reduction overlaps the rest of the backward pass:
+ *   id    = scnattn_dp_unique_id() on rank 0, sent to the other ranks by any out-of-band channel (128 bytes);
+ *   comm  = scnattn_dp_comm_create(id, world, rank) on every rank (current HIP device; collective);
+ *   scnattn_dp_comm_allreduce_bucket(comm, compute_stream, buf, n): in-place SUM of n floats once everything enqueued
+ *           on compute_stream so far has run; returns at once;
+ *   scnattn_dp_comm_finish(comm, compute_stream): compute_stream waits for every bucket handed over so far
+ *           (call before the optimizer reads the gradients; the 1/world scale is folded into scnattn_clamp_adam);
+ *   scnattn_dp_comm_destroy(comm).
+ * Return codes >= 1000 are 1000 + ncclResult_t. */
+typedef struct scnattn_dp_comm scnattn_dp_comm;
+int scnattn_dp_unique_id(char out[128]);
+int scnattn_dp_comm_create(const char id[128], int world, int rank, scnattn_dp_comm** out);
+int scnattn_dp_comm_allreduce_bucket(scnattn_dp_comm* comm, void* compute_stream, float* buf, long n);
+int scnattn_dp_comm_finish(scnattn_dp_comm* comm, void* compute_stream);
+int scnattn_dp_comm_world(const scnattn_dp_comm* comm);
+int scnattn_dp_comm_destroy(scnattn_dp_comm* comm);
 
 /* utils/optimizer.py:1-11 (element-wise clamp) fused with torch.optim.Adam's update
  * (trains/attention_scn.py:244-252); g is first scaled by gscale (1/world for data parallel). */

@@ -29,7 +29,7 @@ int g_chains = 1;        // 2: the recurrence runs as two independent half-batch
                          //    half-batch launch takes as long as a full one (attn_context 15.1 vs 14.1 us)
 int g_fuse_attn = 0;     // 1: scores+softmax+context+gate as one launch (measured SLOWER: 54.0 vs 47.5 us/step,
                          //    each E-chunk workgroup recomputes all 196 scores through its CU's L2 port)
-extern int g_attn_handoff;   // 1 (default): pooled path runs scores + context as one launch with an in-launch hand-off
+extern int g_attn_handoff;   // 1: pooled path runs scores + context as one launch with an in-launch hand-off (default 0: not faster)
 int g_handoff_check = 0;     // 1: seq_fwd synchronises at its end and reports a hand-off time-out (tests)
 
 // ---- optional in-stream timing of the recurrence loops (bench.py's roofline figure) ------------------

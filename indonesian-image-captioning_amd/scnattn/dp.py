@@ -8,13 +8,71 @@ buckets are cut in flat order and fire as soon as every parameter in them has it
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): buckets are sized (default 32 MiB) so that a
 ring step moves MiB-sized chunks per link, and the division by world size is folded into the fused
 optimizer kernel (grad_scale) instead of a separate pass."""
+import ctypes as C
+import os
+
+import torch
 import torch.distributed as dist
 
 
+class CabiComm:
+    """The library's own RCCL communicator (include/scnattn.h: scnattn_dp_comm_*): communication stream + events live
+    in libscnattn, buckets are reduced in place and the compute stream only waits in `finish()`.  The 128-byte RCCL id
+    travels from rank 0 through the already initialised torch.distributed group (any backend: it is 128 bytes of host
+    data).  Used by GradReducer when SCNATTN_DP_BACKEND=cabi (or backend="cabi")."""
+
+    _shared = {}
+
+    def __init__(self, device):
+        from . import _lib
+        self.h = _lib.lib()
+        self._lib = _lib
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            _lib.check(self.h.scnattn_dp_unique_id(buf), "scnattn_dp_unique_id")
+        if world > 1:
+            t = torch.tensor(list(buf.raw), dtype=torch.uint8)
+            if dist.get_backend() == "nccl":
+                t = t.to(device)
+            dist.broadcast(t, src=0)
+            buf = C.create_string_buffer(bytes(t.cpu().tolist()), 128)
+        torch.cuda.set_device(device)
+        handle = C.c_void_p()
+        _lib.check(self.h.scnattn_dp_comm_create(buf, world, rank, C.byref(handle)), "scnattn_dp_comm_create")
+        self.handle, self.world, self.device = handle, world, device
+
+    @classmethod
+    def get(cls, device):
+        key = str(device)
+        if key not in cls._shared:
+            cls._shared[key] = cls(device)
+        return cls._shared[key]
+
+    def _stream(self):
+        return C.c_void_p(torch._C._cuda_getCurrentRawStream(self.device.index))
+
+    def allreduce(self, t):
+        self._lib.check(self.h.scnattn_dp_comm_allreduce_bucket(self.handle, self._stream(), C.c_void_p(t.data_ptr()),
+                                                                t.numel()), "scnattn_dp_comm_allreduce_bucket")
+
+    def finish(self):
+        self._lib.check(self.h.scnattn_dp_comm_finish(self.handle, self._stream()), "scnattn_dp_comm_finish")
+
+    def close(self):
+        if self.handle:
+            self.h.scnattn_dp_comm_destroy(self.handle)
+            self.handle = None
+            CabiComm._shared.pop(str(self.device), None)
+
+
 class GradReducer:
-    def __init__(self, flat, bucket_bytes=32 << 20, group=None):
+    def __init__(self, flat, bucket_bytes=32 << 20, group=None, backend=None):
         self.flat = flat
         self.group = group
+        backend = backend or os.environ.get("SCNATTN_DP_BACKEND", "torch")
+        self.cabi = CabiComm.get(flat.flat_g.device) if (backend == "cabi" and flat.flat_g.is_cuda) else None
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.buckets = []      # (start, end, [param indices])
         start, idxs, limit = 0, [], max(1, bucket_bytes // 4)
@@ -51,8 +109,11 @@ class GradReducer:
     def _launch(self, b):
         s, e, idxs = self.buckets[b]
         self.flat.gather(idxs)            # one multi-tensor copy of the bucket's gradients
-        self.works.append(dist.all_reduce(self.flat.flat_g[s:e], op=dist.ReduceOp.SUM, group=self.group,
-                                          async_op=True))
+        if self.cabi is not None:         # RCCL through the C ABI: library-owned comm stream, event-ordered
+            self.cabi.allreduce(self.flat.flat_g[s:e])
+        else:
+            self.works.append(dist.all_reduce(self.flat.flat_g[s:e], op=dist.ReduceOp.SUM, group=self.group,
+                                              async_op=True))
         self.launched[b] = True
 
     def reset(self):
@@ -72,6 +133,8 @@ class GradReducer:
         for w in self.works:
             w.wait()
         self.works = []
+        if self.cabi is not None:
+            self.cabi.finish()
         return 1.0 / self.world
 
 

@@ -626,3 +626,47 @@ def test_attention_handoff_launch_is_bit_identical_to_two_launches(dev, B, ragge
     for k in res[0][3]:
         assert torch.equal(res[0][3][k], res[1][3][k]), k
     assert abs(res[0][1][0, 0].sum().item() - 1.0) < 1e-5
+
+
+def test_dp_comm_through_the_c_abi_single_rank(dev):
+    """include/scnattn.h scnattn_dp_comm_*: RCCL bound at run time, a communicator of one rank on the library's own
+    communication stream, bucketed in-place SUM all-reduce ordered by events against the compute stream, and
+    GradReducer driving it (backend="cabi") from post-accumulate hooks: gradients must come out unchanged (world 1),
+    bucket after bucket, with the compute stream waiting only in finish().  A 1-GPU box cannot host two RCCL ranks
+    (one device per rank); the N-rank arithmetic is covered by the gloo tests, the RCCL path with N ranks by the
+    driver's scaling run."""
+    import ctypes as C
+    from scnattn import _lib
+    from scnattn.dp import CabiComm, GradReducer
+    from scnattn.flat import FlatBuffer
+    comm = CabiComm.get(dev)
+    assert comm.world == 1 and _lib.lib().scnattn_dp_comm_world(comm.handle) == 1
+    t = torch.randn(1 << 20, device=dev)
+    ref = t.clone()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):         # a non-default compute stream: the event ordering must hold there too
+        t.mul_(2.0)
+        comm.allreduce(t)
+        comm.allreduce(t[:1000])
+        comm.finish()
+        out = t + 0.0
+    side.synchronize()
+    assert torch.equal(out, ref * 2.0)
+    # GradReducer with the C-ABI backend on a small model
+    lin = torch.nn.Sequential(torch.nn.Linear(64, 256), torch.nn.Linear(256, 8)).to(dev)
+    flat = FlatBuffer(lin.parameters())
+    red = GradReducer(flat, bucket_bytes=4096, backend="cabi")
+    red.enabled = True
+    x = torch.randn(16, 64, device=dev)
+    red.reset()
+    lin(x).square().sum().backward()
+    scale = red.finish()
+    flat.gather()
+    torch.cuda.synchronize()
+    assert scale == 1.0 and len(red.buckets) > 1
+    lin2 = torch.nn.Sequential(torch.nn.Linear(64, 256), torch.nn.Linear(256, 8)).to(dev)
+    lin2.load_state_dict(lin.state_dict())
+    lin2(x).square().sum().backward()
+    for p, q in zip(lin.parameters(), lin2.parameters()):
+        assert torch.equal(p.grad, q.grad)
+    comm.close()
