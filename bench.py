@@ -310,7 +310,10 @@ def main():
                 last_loss[0] = ts.step(imgs, tags, caps, caplens, enc_in, pre_in, drop_in=drop_in[0])
 
     drop_in = [bool(args.drop_in_call)]
+    dbg = (lambda m: print("[bench] " + m, file=sys.stderr, flush=True)) if os.environ.get("BENCH_DEBUG") else (lambda m: None)
+    dbg("built; warm-up")
     run(args.warmup)
+    dbg("warm-up done")
     SF.set_option("profile", 1)
     prof = (ctypes.c_double * 6)()
     torch.cuda.synchronize()
@@ -325,6 +328,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    dbg("timed region done")
     _lib.call("scnattn_profile_collect", prof)
     # outside the timed region: per-launch HIP-event timing of the dominant single kernel (attn_context)
     ctx_us, ctx_per_step = None, 1.0
@@ -363,6 +367,7 @@ def main():
         if elapsed_di is not None:
             elapsed_di = float(tmax[1].item())
 
+    dbg("reductions done")
     if last_loss[0] is not None:     # outside the timed region: the model must still be training on finite numbers
         final_loss = float(last_loss[0].detach())
         assert final_loss == final_loss and abs(final_loss) < 1e6, "loss diverged: %r" % final_loss
@@ -462,7 +467,8 @@ def main():
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)      # the LAST stdout line (RCCL may print a version banner before it)
     if dist_on:
         dist.destroy_process_group()
 
