@@ -108,10 +108,28 @@ class GradReducer:
 
     def _launch(self, b):
         s, e, idxs = self.buckets[b]
-        self.flat.gather(idxs)            # one multi-tensor copy of the bucket's gradients
-        if self.cabi is not None:         # RCCL through the C ABI: library-owned comm stream, event-ordered
-            self.cabi.allreduce(self.flat.flat_g[s:e])
+        if self.flat.flat_g.is_cuda:
+            # The bucket's gather copy and its all-reduce are enqueued on the SIDE stream that also carries the trunk's
+            # weight gradients (scnattn/conv.py): that stream first waits for what the main stream has produced so far
+            # (an event), the main stream itself never waits for a bucket -- it carries on with the d-input chain --
+            # and only `finish()` joins.  (Joining the main stream here instead cost 18 % of the step at one rank.)
+            from . import conv as _conv
+            dev = self.flat.flat_g.device
+            side = _conv._side(dev)
+            main = torch.cuda.current_stream(dev)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.stream.wait_event(ev)
+            with torch.cuda.stream(side.stream):
+                self.flat.gather(idxs, join=False, record_stream=side.stream)
+                if self.cabi is not None:     # RCCL through the C ABI: library-owned comm stream, event-ordered
+                    self.cabi.allreduce(self.flat.flat_g[s:e])
+                else:
+                    self.works.append(dist.all_reduce(self.flat.flat_g[s:e], op=dist.ReduceOp.SUM, group=self.group,
+                                                      async_op=True))
+            side.mark()
         else:
+            self.flat.gather(idxs)            # one multi-tensor copy of the bucket's gradients
             self.works.append(dist.all_reduce(self.flat.flat_g[s:e], op=dist.ReduceOp.SUM, group=self.group,
                                               async_op=True))
         self.launched[b] = True
@@ -133,8 +151,11 @@ class GradReducer:
         for w in self.works:
             w.wait()
         self.works = []
-        if self.cabi is not None:
-            self.cabi.finish()
+        if self.flat.flat_g.is_cuda:
+            from . import conv as _conv
+            _conv.join_side_streams()
+            if self.cabi is not None:
+                self.cabi.finish()
         return 1.0 / self.world
 
 

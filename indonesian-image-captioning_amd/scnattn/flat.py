@@ -38,10 +38,12 @@ class FlatBuffer:
         for p in self.params:
             p.grad = None
 
-    def gather(self, indices=None):
+    def gather(self, indices=None, join=True, record_stream=None):
         """Copy the gradients autograd produced for parameters `indices` (default: all) into the flat
-        buffer and make each ``.grad`` the flat view.  Parameters that received no gradient get zeros."""
-        if self.flat_g.is_cuda:
+        buffer and make each ``.grad`` the flat view.  Parameters that received no gradient get zeros.
+        `join=False`: the caller runs on the side stream that produced the weight gradients itself (data-parallel
+        buckets), so nothing has to wait; `record_stream` then keeps the source tensors alive for that stream."""
+        if self.flat_g.is_cuda and join:
             from . import conv as _conv
             _conv.join_side_streams()     # weight gradients of the fused Bottleneck run on a side stream
         idx = range(len(self.params)) if indices is None else indices
@@ -51,6 +53,8 @@ class FlatBuffer:
             if p.grad is None:
                 gv.zero_()
             elif p.grad.data_ptr() != gv.data_ptr():
+                if record_stream is not None:
+                    p.grad.record_stream(record_stream)
                 src.append(p.grad)
                 dst.append(gv)
             p.grad = gv
