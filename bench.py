@@ -219,6 +219,8 @@ def main():
     ap.add_argument("--dp-backend", default=os.environ.get("SCNATTN_DP_BACKEND", "torch"), choices=["torch", "cabi"],
                     help="gradient all-reduce through torch.distributed (RCCL) or through the library's own RCCL "
                          "communicator (include/scnattn.h scnattn_dp_comm_*)")
+    ap.add_argument("--bucket-mb", type=int, default=32, help="data-parallel all-reduce bucket size (MiB)")
+    ap.add_argument("--no-side-wgrad", action="store_true", help="A/B: weight gradients on the main stream")
     ap.add_argument("--attn-handoff", type=int, default=0,
                     help="0: attention scores and context as two launches (A/B of the in-launch hand-off)")
     ap.add_argument("--drop-in-call", action="store_true",
@@ -257,6 +259,9 @@ def main():
         _conv.ENABLED = False
     if args.no_cgemm:
         SF.set_option("use_cgemm", 0)
+    if args.no_side_wgrad:
+        from scnattn import conv as _conv2
+        _conv2.SIDE_WGRAD = False
     SF.set_option("attn_handoff", args.attn_handoff)
     if args.ksplit:
         SF.set_option("ksplit", args.ksplit)
@@ -280,7 +285,7 @@ def main():
         dist.barrier()                                    # first collective on every rank
     ts = TrainStep(kind=args.workload, fine_tune_encoder=fine_tune, device=dev, encoder=not args.decoder_only,
                    batch_size=args.batch, max_len=args.max_len, graph_encoder=args.graph, tagger=args.with_tagger, force_reduce=args.force_dist,
-                   encoder_dtype=args.encoder_dtype, pooled_attention=not args.dense_attention)
+                   encoder_dtype=args.encoder_dtype, pooled_attention=not args.dense_attention, bucket_mb=args.bucket_mb)
     cfg = ts.cfg
     imgs, tags, caps, caplens = synthetic_batch(args.batch, cfg["vocab_size"], cfg["max_len"], cfg["image_size"],
                                                 cfg["semantic_dim"], dev, 1234 + rank)

@@ -298,6 +298,35 @@ int scnattn_conv3x3_dgrad(void* stream, int N, int Hi, int Wi, int Cin, int Cout
                           float* dx, const scnattn_conv_extra* ex, float* ws, long ws_floats);
 int scnattn_conv3x3_wgrad(void* stream, int N, int Hi, int Wi, int Cin, int Cout, int stride, const float* dy,
                           const float* x, float* dw, float* ws, long ws_floats);
+/* ---- whole-block drivers (csrc/bottleneck.cpp): ONE call enqueues every kernel of a Bottleneck's forward pass, ONE its
+ * backward pass -- torchvision's Bottleneck behind models/encoders/caption.py:17-22, out = relu(bn3(conv3(relu(bn2(
+ * conv2(relu(bn1(conv1(x)))))))) + identity) with BatchNorm in training mode -- the way scnattn_seq_fwd/bwd do for the
+ * decoder's time loop.  fp32 channels-last maps ([N*H*W][C]); w1 [P][Cin], w2 [P][3][3][P], w3 [4P][P], wd [4P][Cin]
+ * (channels-last conv weights); rm1.. / rv1.. = running mean / variance (updated with mom1..), eps / mom per BatchNorm.
+ * Workspaces come from the caller (scnattn_block_sizes): `saved` carries the forward state to the backward pass,
+ * `scratch` is free after the call; ws / ws_side = split-K slabs of the GEMMs on the main / side stream (>= 16 Mi
+ * floats), part >= 2 Mi floats, bnpart >= scnattn_bn_workspace_floats(4P). */
+typedef struct scnattn_block {
+    int N, Hi, Wi, Cin, P, stride, has_down;      /* P = planes; output channels = 4P */
+    float eps1, mom1, eps2, mom2, eps3, mom3, epsd, momd;
+    const float *w1, *g1, *b1, *w2, *g2, *b2, *w3, *g3, *b3, *wd, *gd, *bd;
+    float *rm1, *rv1, *rm2, *rv2, *rm3, *rv3, *rmd, *rvd;
+} scnattn_block;
+/* weight gradients the backward driver writes itself (NULL = skip); the BatchNorm gradients are left in `scratch` at
+ * offsets[5] as {dbeta1 [P], dgamma1 [P], dbeta2, dgamma2, dbeta3 [4P], dgamma3 [4P]} */
+typedef struct scnattn_block_grads {
+    float *dw1, *dw3;
+} scnattn_block_grads;
+/* offsets (floats): [0] a1 in saved, [1] dz2 in scratch (both inputs of the 3x3 weight gradient, which the caller
+ * runs), [2] z2, [3] z1, [4] z3 in saved, [5] BatchNorm gradients in scratch, [6] dz3, [7] dz1 in scratch */
+int scnattn_block_sizes(const scnattn_block* b, size_t* saved_floats, size_t* scratch_floats, long offsets[8]);
+int scnattn_block_fwd(void* stream, const scnattn_block* b, const float* x, float* saved, float* out, float* ws,
+                      long ws_floats, float* part, float* bnpart);
+/* identity blocks only (no downsample, stride 1).  dx [N*Hi*Wi][Cin] may be NULL; the two 1x1 weight gradients run on
+ * side_stream (NULL: on `stream`), forked by events once their inputs exist -- the caller joins before reading them. */
+int scnattn_block_bwd(void* stream, void* side_stream, const scnattn_block* b, const float* x, const float* saved,
+                      const float* out, const float* dout, float* scratch, float* dx, const scnattn_block_grads* gr,
+                      float* ws, float* ws_side, long ws_floats, float* part, float* bnpart);
 /* BatchNorm statistics from partial[nchunk][2][C] = {sum(x - s), sum((x - s)^2)} (s = shift[c] or 0), as written by
  * the statistics epilogue above: mean, 1/sqrt(var+eps), running-stat update (momentum; run_* may be NULL), and, when
  * ss_out is given, the folded {scale = gamma*invstd, shift = beta - mean*scale} pairs [C][2] for a consumer's prologue. */

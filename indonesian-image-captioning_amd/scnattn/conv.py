@@ -407,6 +407,111 @@ class _BottleneckFn(torch.autograd.Function):
                 (dgbd[0] if need[13] else None) if dgbd is not None else None)
 
 
+C_DRIVER = os.environ.get("SCNATTN_BLOCK_DRIVER", "1") != "0"   # identity blocks: one C call forward, one backward
+_block_sizes = {}
+
+
+def _block_struct(mod, N, Hi, Wi):
+    from ._lib import Block
+    bn1, bn2, bn3 = mod.bn1, mod.bn2, mod.bn3
+    p, cin = mod.conv1.weight.shape[0], mod.conv1.weight.shape[1]
+    b = Block()
+    b.N, b.Hi, b.Wi, b.Cin, b.P, b.stride, b.has_down = N, Hi, Wi, cin, p, mod.stride, 0
+    b.eps1, b.mom1, b.eps2, b.mom2, b.eps3, b.mom3 = bn1.eps, bn1.momentum, bn2.eps, bn2.momentum, bn3.eps, bn3.momentum
+    b.w1, b.g1, b.b1 = mod.conv1.weight.data_ptr(), bn1.weight.data_ptr(), bn1.bias.data_ptr()
+    b.w2, b.g2, b.b2 = mod.conv2.weight.data_ptr(), bn2.weight.data_ptr(), bn2.bias.data_ptr()
+    b.w3, b.g3, b.b3 = mod.conv3.weight.data_ptr(), bn3.weight.data_ptr(), bn3.bias.data_ptr()
+    b.rm1, b.rv1 = bn1.running_mean.data_ptr(), bn1.running_var.data_ptr()
+    b.rm2, b.rv2 = bn2.running_mean.data_ptr(), bn2.running_var.data_ptr()
+    b.rm3, b.rv3 = bn3.running_mean.data_ptr(), bn3.running_var.data_ptr()
+    key = (N, Hi, Wi, cin, p, mod.stride)
+    sz_ = _block_sizes.get(key)
+    if sz_ is None:
+        h, _ = _fns()
+        sv, sc = C.c_size_t(), C.c_size_t()
+        offs = (C.c_long * 8)()
+        _chk(h.scnattn_block_sizes(C.byref(b), C.byref(sv), C.byref(sc), offs), "scnattn_block_sizes")
+        sz_ = _block_sizes[key] = (sv.value, sc.value, tuple(offs))
+    return b, sz_
+
+
+class _BlockFnC(torch.autograd.Function):
+    """An identity Bottleneck (no downsample, stride 1) through csrc/bottleneck.cpp: ONE C call enqueues the ~15 forward
+    kernels, ONE the ~25 backward kernels (3x3 conv2 forward / d input as implicit GEMMs of the same kernel family);
+    only conv2's weight gradient is left to MIOpen, on the side stream."""
+
+    @staticmethod
+    def forward(ctx, mod, x, w1, g1, b1, w2, g2, b2, w3, g3, b3):
+        h, raw_stream = _fns()
+        dev = x.device
+        st = raw_stream(dev.index)
+        ws, part, bnpart = _buffers(dev)
+        if not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)
+        N, Cin, Hi, Wi = x.shape
+        blk, (svf, scf, offs) = _block_struct(mod, N, Hi, Wi)
+        saved = torch.empty(svf, device=dev, dtype=torch.float32)
+        out = torch.empty((N * Hi * Wi, Cin), device=dev, dtype=torch.float32)
+        _chk(h.scnattn_block_fwd(st, C.byref(blk), x.data_ptr(), saved.data_ptr(), out.data_ptr(), ws.data_ptr(),
+                                 ws.numel(), part.data_ptr(), bnpart.data_ptr()), "scnattn_block_fwd")
+        ctx.mod = mod
+        ctx.geom = (N, Cin, Hi, Wi)
+        ctx.save_for_backward(x, saved, out, w1, g1, b1, w2, g2, b2, w3, g3, b3)
+        return _as4d(out, N, Hi, Wi)
+
+    @staticmethod
+    def backward(ctx, dout):
+        from ._lib import BlockGrads
+        h, raw_stream = _fns()
+        x, saved, out, w1, g1, b1, w2, g2, b2, w3, g3, b3 = ctx.saved_tensors
+        mod = ctx.mod
+        N, Cin, Hi, Wi = ctx.geom
+        dev = x.device
+        st = raw_stream(dev.index)
+        ws, part, bnpart = _buffers(dev)
+        need = ctx.needs_input_grad      # (mod, x, w1, g1, b1, w2, g2, b2, w3, g3, b3)
+        if dout.dtype != torch.float32 or not dout.is_contiguous(memory_format=torch.channels_last):
+            dout = dout.float().contiguous(memory_format=torch.channels_last)
+        blk, (svf, scf, offs) = _block_struct(mod, N, Hi, Wi)
+        p = blk.P
+        R = N * Hi * Wi
+        scratch = torch.empty(scf, device=dev, dtype=torch.float32)
+        dx = torch.empty((R, Cin), device=dev, dtype=torch.float32)      # always: it first receives d identity
+        dw1 = torch.empty_like(w1) if need[2] else None
+        dw3 = torch.empty_like(w3) if need[8] else None
+        gr = BlockGrads(None if dw1 is None else dw1.data_ptr(), None if dw3 is None else dw3.data_ptr())
+        main = torch.cuda.current_stream(dev)
+        side = _side(dev) if SIDE_WGRAD else None
+        if side is not None:
+            for t_ in (scratch, saved, x, dw1, dw3):
+                if t_ is not None:
+                    t_.record_stream(side.stream)
+        _chk(h.scnattn_block_bwd(st, None if side is None else side.stream.cuda_stream, C.byref(blk), x.data_ptr(),
+                                 saved.data_ptr(), out.data_ptr(), dout.data_ptr(), scratch.data_ptr(), dx.data_ptr(),
+                                 C.byref(gr), ws.data_ptr(), None if side is None else side.ws.data_ptr(), ws.numel(),
+                                 part.data_ptr(), bnpart.data_ptr()), "scnattn_block_bwd")
+        dw2 = None
+        if need[5]:      # conv2's weight gradient: MIOpen, on the side stream, from dz2 (scratch) and a1 (saved)
+            a1_4 = _as4d(saved[offs[0]:offs[0] + R * p].view(R, p), N, Hi, Wi)
+            dz2_4 = _as4d(scratch[offs[1]:offs[1] + R * p].view(R, p), N, Hi, Wi)
+            if side is not None:
+                side.fork(main)
+                with torch.cuda.stream(side.stream):
+                    dw2 = torch.ops.aten.convolution_backward(dz2_4, a1_4, w2, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                              [False, True, False])[1]
+            else:
+                dw2 = torch.ops.aten.convolution_backward(dz2_4, a1_4, w2, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                          [False, True, False])[1]
+        if side is not None:
+            side.mark()
+        gb = scratch[offs[5]:offs[5] + 4 * p + 8 * p]
+        db1, dg1, db2, dg2 = gb[0:p], gb[p:2 * p], gb[2 * p:3 * p], gb[3 * p:4 * p]
+        db3, dg3 = gb[4 * p:8 * p], gb[8 * p:12 * p]
+        return (None, _as4d(dx, N, Hi, Wi) if need[1] else None, dw1, dg1 if need[3] else None, db1 if need[4] else None,
+                dw2, dg2 if need[6] else None, db2 if need[7] else None, dw3, dg3 if need[9] else None,
+                db3 if need[10] else None)
+
+
 def usable(mod, x):
     """The fused path covers what the train step runs: fp32 CUDA maps, BatchNorm in training mode with running
     statistics and affine parameters, widths that the 16-byte LDS-DMA granules can address."""
@@ -434,5 +539,9 @@ def bottleneck(mod, x):
         wd, gd, bd = mod.downsample[0].weight, mod.downsample[1].weight, mod.downsample[1].bias
     else:
         wd = gd = bd = None
+        if C_DRIVER and mod.stride == 1 and mod.conv2.weight.is_contiguous(memory_format=torch.channels_last) \
+                and mod.conv1.weight.shape[1] == 4 * mod.conv1.weight.shape[0]:
+            return _BlockFnC.apply(mod, x, mod.conv1.weight, mod.bn1.weight, mod.bn1.bias, mod.conv2.weight,
+                                   mod.bn2.weight, mod.bn2.bias, mod.conv3.weight, mod.bn3.weight, mod.bn3.bias)
     return _BottleneckFn.apply(mod, x, mod.conv1.weight, mod.bn1.weight, mod.bn1.bias, mod.conv2.weight, mod.bn2.weight,
                                mod.bn2.bias, mod.conv3.weight, mod.bn3.weight, mod.bn3.bias, wd, gd, bd)
