@@ -326,7 +326,9 @@ int scnattn_block_fwd(void* stream, const scnattn_block* b, const float* x, floa
  * side_stream (NULL: on `stream`), forked by events once their inputs exist -- the caller joins before reading them. */
 int scnattn_block_bwd(void* stream, void* side_stream, const scnattn_block* b, const float* x, const float* saved,
                       const float* out, const float* dout, float* scratch, float* dx, const scnattn_block_grads* gr,
-                      float* ws, float* ws_side, long ws_floats, float* part, float* bnpart);
+                      float* ws, float* ws_side, long ws_floats, float* part, float* bnpart, int phase);
+/* phase 0: the whole backward pass; 1: up to dz2 (so that the caller can start conv2's weight gradient, the longest one,
+ * as early as its inputs exist); 2: the rest. */
 /* BatchNorm statistics from partial[nchunk][2][C] = {sum(x - s), sum((x - s)^2)} (s = shift[c] or 0), as written by
  * the statistics epilogue above: mean, 1/sqrt(var+eps), running-stat update (momentum; run_* may be NULL), and, when
  * ss_out is given, the folded {scale = gamma*invstd, shift = beta - mean*scale} pairs [C][2] for a consumer's prologue. */

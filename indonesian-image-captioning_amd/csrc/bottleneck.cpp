@@ -194,7 +194,7 @@ int scnattn_block_fwd(void* stream, const scnattn_block* b, const float* x, floa
 
 int scnattn_block_bwd(void* stream, void* side_stream, const scnattn_block* b, const float* x, const float* saved,
                       const float* out, const float* dout, float* scratch, float* dx, const scnattn_block_grads* gr,
-                      float* ws, float* ws_side, long ws_floats, float* part, float* bnpart) {
+                      float* ws, float* ws_side, long ws_floats, float* part, float* bnpart, int phase) {
     SCN_TRY(check_block(b));
     SCN_ARG(!b->has_down && b->stride == 1, "block_bwd: identity blocks only (no downsample, stride 1)");
     SCN_ARG(x && saved && out && dout && scratch && gr && ws && part && bnpart, "block_bwd: NULL argument");
@@ -208,6 +208,7 @@ int scnattn_block_bwd(void* stream, void* side_stream, const scnattn_block* b, c
     carve_scratch(*b, scratch, k);
     const int P = b->P, C4 = g.C4, Cin = b->Cin, R = g.Rout;
     float *dgb1 = k.gb, *dgb2 = k.gb + 2 * P, *dgb3 = k.gb + 4 * P;     // each {dbeta [C], dgamma [C]}
+    if (phase != 2) {
     // bn3 (+ identity + relu): dz3 and the identity branch's gradient, straight into the dx buffer
     SCN_TRY(bn_bwd(st, R, C4, dout, out, s.z3, 0, s.st3, s.st3 + C4, b->g3, nullptr, 1, 1, bnpart, dgb3, dgb3 + C4, k.dz3, dx));
     // conv3 weight gradient on the side stream, a2 = relu(bn2(z2)) recomputed on load
@@ -224,6 +225,8 @@ int scnattn_block_bwd(void* stream, void* side_stream, const scnattn_block* b, c
         SCN_TRY(bn_bwd_finalize(st, P, cgemm_row_tiles(R), part, dgb2, dgb2 + P));
         SCN_TRY(bn_bwd_dx(st, R, P, k.g2, s.z2, s.st2, s.st2 + P, b->g2, dgb2, dgb2 + P, k.g2));
     }
+    }   // phase != 2
+    if (phase == 1) return 0;      // dz2 is ready: the caller forks conv2's weight gradient here, then calls phase 2
     // conv2 d input (implicit GEMM, stride 1); its weight gradient is the caller's (side stream) -- dz2 = k.g2, a1 saved
     {
         ConvExtra e; e.c3 = 2; e.c3c = P; e.c3_src_rows = R; e.Hi = b->Hi; e.Wi = b->Wi; e.Ho = b->Hi; e.Wo = b->Wi; e.stride = 1;

@@ -87,7 +87,7 @@ _SIGS = {
     "scnattn_conv3x3_wgrad": ([vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i64], i32),
     "scnattn_block_sizes": ([C.POINTER(Block), C.POINTER(sz), C.POINTER(sz), C.POINTER(C.c_long)], i32),
     "scnattn_block_fwd": ([vp, C.POINTER(Block), vp, vp, vp, vp, i64, vp, vp], i32),
-    "scnattn_block_bwd": ([vp, vp, C.POINTER(Block), vp, vp, vp, vp, vp, vp, C.POINTER(BlockGrads), vp, vp, i64, vp, vp], i32),
+    "scnattn_block_bwd": ([vp, vp, C.POINTER(Block), vp, vp, vp, vp, vp, vp, C.POINTER(BlockGrads), vp, vp, i64, vp, vp, i32], i32),
     "scnattn_bn_finalize": ([vp, i64, i32, i32, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp], i32),
     "scnattn_bn_bwd_finalize": ([vp, i32, i32, vp, vp, vp], i32),
     "scnattn_bn_stats_fold": ([vp, i32, i32, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp], i32),

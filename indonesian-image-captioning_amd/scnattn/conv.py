@@ -409,6 +409,24 @@ class _BottleneckFn(torch.autograd.Function):
 
 C_DRIVER = os.environ.get("SCNATTN_BLOCK_DRIVER", "1") != "0"   # identity blocks: one C call forward, one backward
 _block_sizes = {}
+_scratch_rings = {}
+
+
+def _scratch(dev, nfloats, main):
+    """Backward scratch of the block driver from a ring of three buffers per size.  A fresh torch.empty per call would
+    have to be record_stream()-ed for the side stream, and with the host now far ahead of the GPU the caching allocator
+    could not reuse such blocks in time (it falls back to hipMalloc, which stalls the device).  A ring slot is reused two
+    blocks later; the main stream first waits for the event the side stream recorded when it last used the slot."""
+    key = (dev, nfloats)
+    ring = _scratch_rings.get(key)
+    if ring is None:
+        ring = _scratch_rings[key] = {"i": 0, "slots": [[torch.empty(nfloats, device=dev, dtype=torch.float32), None]
+                                                         for _ in range(3)]}
+    slot = ring["slots"][ring["i"]]
+    ring["i"] = (ring["i"] + 1) % 3
+    if slot[1] is not None:
+        main.wait_event(slot[1])
+    return slot
 
 
 def _block_struct(mod, N, Hi, Wi):
@@ -475,23 +493,27 @@ class _BlockFnC(torch.autograd.Function):
         blk, (svf, scf, offs) = _block_struct(mod, N, Hi, Wi)
         p = blk.P
         R = N * Hi * Wi
-        scratch = torch.empty(scf, device=dev, dtype=torch.float32)
+        main = torch.cuda.current_stream(dev)
+        slot = _scratch(dev, scf, main)
+        scratch = slot[0]
         dx = torch.empty((R, Cin), device=dev, dtype=torch.float32)      # always: it first receives d identity
         dw1 = torch.empty_like(w1) if need[2] else None
         dw3 = torch.empty_like(w3) if need[8] else None
         gr = BlockGrads(None if dw1 is None else dw1.data_ptr(), None if dw3 is None else dw3.data_ptr())
-        main = torch.cuda.current_stream(dev)
         side = _side(dev) if SIDE_WGRAD else None
         if side is not None:
-            for t_ in (scratch, saved, x, dw1, dw3):
+            for t_ in (saved, x, dw1, dw3):
                 if t_ is not None:
                     t_.record_stream(side.stream)
-        _chk(h.scnattn_block_bwd(st, None if side is None else side.stream.cuda_stream, C.byref(blk), x.data_ptr(),
-                                 saved.data_ptr(), out.data_ptr(), dout.data_ptr(), scratch.data_ptr(), dx.data_ptr(),
-                                 C.byref(gr), ws.data_ptr(), None if side is None else side.ws.data_ptr(), ws.numel(),
-                                 part.data_ptr(), bnpart.data_ptr()), "scnattn_block_bwd")
+        def run(phase):
+            _chk(h.scnattn_block_bwd(st, None if side is None else side.stream.cuda_stream, C.byref(blk), x.data_ptr(),
+                                     saved.data_ptr(), out.data_ptr(), dout.data_ptr(), scratch.data_ptr(), dx.data_ptr(),
+                                     C.byref(gr), ws.data_ptr(), None if side is None else side.ws.data_ptr(), ws.numel(),
+                                     part.data_ptr(), bnpart.data_ptr(), phase), "scnattn_block_bwd")
+
         dw2 = None
-        if need[5]:      # conv2's weight gradient: MIOpen, on the side stream, from dz2 (scratch) and a1 (saved)
+        if need[5]:      # conv2's weight gradient: MIOpen, on the side stream, as soon as dz2 (scratch) exists
+            run(1)
             a1_4 = _as4d(saved[offs[0]:offs[0] + R * p].view(R, p), N, Hi, Wi)
             dz2_4 = _as4d(scratch[offs[1]:offs[1] + R * p].view(R, p), N, Hi, Wi)
             if side is not None:
@@ -502,9 +524,14 @@ class _BlockFnC(torch.autograd.Function):
             else:
                 dw2 = torch.ops.aten.convolution_backward(dz2_4, a1_4, w2, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                                                           [False, True, False])[1]
+            run(2)
+        else:
+            run(0)
         if side is not None:
             side.mark()
-        gb = scratch[offs[5]:offs[5] + 4 * p + 8 * p]
+            slot[1] = side.pending        # the ring slot may be rewritten once the side stream got here
+        # the BatchNorm gradients leave the ring slot (it is rewritten two blocks later): one small copy
+        gb = scratch[offs[5]:offs[5] + 12 * p].clone()
         db1, dg1, db2, dg2 = gb[0:p], gb[p:2 * p], gb[2 * p:3 * p], gb[3 * p:4 * p]
         db3, dg3 = gb[4 * p:8 * p], gb[8 * p:12 * p]
         return (None, _as4d(dx, N, Hi, Wi) if need[1] else None, dw1, dg1 if need[3] else None, db1 if need[4] else None,
@@ -539,8 +566,10 @@ def bottleneck(mod, x):
         wd, gd, bd = mod.downsample[0].weight, mod.downsample[1].weight, mod.downsample[1].bias
     else:
         wd = gd = bd = None
+        # (64-channel 3x3 convolutions -- layer1 -- are the one shape where MIOpen's kernel wins clearly: those blocks
+        #  keep the per-call path with its autotuned conv2)
         if C_DRIVER and mod.stride == 1 and mod.conv2.weight.is_contiguous(memory_format=torch.channels_last) \
-                and mod.conv1.weight.shape[1] == 4 * mod.conv1.weight.shape[0]:
+                and mod.conv1.weight.shape[1] == 4 * mod.conv1.weight.shape[0] and mod.conv1.weight.shape[0] >= 128:
             return _BlockFnC.apply(mod, x, mod.conv1.weight, mod.bn1.weight, mod.bn1.bias, mod.conv2.weight,
                                    mod.bn2.weight, mod.bn2.bias, mod.conv3.weight, mod.bn3.weight, mod.bn3.bias)
     return _BottleneckFn.apply(mod, x, mod.conv1.weight, mod.bn1.weight, mod.bn1.bias, mod.conv2.weight, mod.bn2.weight,
