@@ -185,6 +185,13 @@ def _finalize(h, st, R, Cn, part, bn_mod, training, gamma, beta, want_ss):
     return stats, ss
 
 
+def _grad_out(w):
+    """Where a weight gradient is written: the parameter's slice of the flat gradient buffer when it has one
+    (scnattn/flat.py; saves the optimizer's gather copy), a fresh tensor otherwise."""
+    gv = getattr(w, "_scn_flat_grad", None)
+    return gv if gv is not None else torch.empty_like(w)
+
+
 def _wt(h, st, w, cout, cin):
     """[Cout][Cin] 1x1 weight -> [Cin][Cout] (<= 4 MB, one small kernel): conv1's d input then runs with both operands
     on the k-contiguous LDS image (a [K][N] weight with N = Cin large is the slow layout: 56 vs 40 us on layer3)."""
@@ -303,7 +310,7 @@ class _BottleneckFn(torch.autograd.Function):
         side = _side(dev) if SIDE_WGRAD else None
         dw3 = None
         if need[8]:
-            dw3 = torch.empty_like(w3)
+            dw3 = _grad_out(w3)
             ex = ConvExtra(pro=2, pro_ss=ss2.data_ptr())
             sw, wsw = (side.fork(main, dz3, z2, ss2, dw3), side.ws) if side else (st, ws)
             _chk(h.scnattn_conv1x1_wgrad(sw, Rout, p, C4, dz3.data_ptr(), z2.data_ptr(), dw3.data_ptr(), C.byref(ex),
@@ -364,7 +371,7 @@ class _BottleneckFn(torch.autograd.Function):
                               dz1.data_ptr(), None), "scnattn_bn_bwd")
         dw1 = None
         if need[2]:
-            dw1 = torch.empty_like(w1)
+            dw1 = _grad_out(w1)
             sw, wsw = (side.fork(main, dz1, x, dw1), side.ws) if side else (st, ws)
             _chk(h.scnattn_conv1x1_wgrad(sw, Rin, Cin, p, dz1.data_ptr(), x2.data_ptr(), dw1.data_ptr(), None,
                                          wsw.data_ptr(), wsw.numel()), "scnattn_conv1x1_wgrad")
@@ -378,7 +385,7 @@ class _BottleneckFn(torch.autograd.Function):
                                   std[1].data_ptr(), gd.data_ptr(), None, 0, 1, bnpart.data_ptr(), dgbd[0].data_ptr(),
                                   dgbd[1].data_ptr(), dzd.data_ptr(), None), "scnattn_bn_bwd")
             if need[11]:
-                dwd = torch.empty_like(wd)
+                dwd = _grad_out(wd)
                 ex = ConvExtra(stride=s, Hi=Hi, Wi=Wi, Ho=Ho, Wo=Wo)
                 sw, wsw = (side.fork(main, dzd, x, dwd), side.ws) if side else (st, ws)
                 _chk(h.scnattn_conv1x1_wgrad(sw, Rout, Cin, C4, dzd.data_ptr(), x2.data_ptr(), dwd.data_ptr(),
@@ -497,14 +504,13 @@ class _BlockFnC(torch.autograd.Function):
         slot = _scratch(dev, scf, main)
         scratch = slot[0]
         dx = torch.empty((R, Cin), device=dev, dtype=torch.float32)      # always: it first receives d identity
-        dw1 = torch.empty_like(w1) if need[2] else None
-        dw3 = torch.empty_like(w3) if need[8] else None
+        dw1 = _grad_out(w1) if need[2] else None
+        dw3 = _grad_out(w3) if need[8] else None
         gr = BlockGrads(None if dw1 is None else dw1.data_ptr(), None if dw3 is None else dw3.data_ptr())
         side = _side(dev) if SIDE_WGRAD else None
         if side is not None:
-            for t_ in (saved, x, dw1, dw3):
-                if t_ is not None:
-                    t_.record_stream(side.stream)
+            for t_ in (saved, x):
+                t_.record_stream(side.stream)
         def run(phase):
             _chk(h.scnattn_block_bwd(st, None if side is None else side.stream.cuda_stream, C.byref(blk), x.data_ptr(),
                                      saved.data_ptr(), out.data_ptr(), dout.data_ptr(), scratch.data_ptr(), dx.data_ptr(),

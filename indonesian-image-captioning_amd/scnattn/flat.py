@@ -32,6 +32,9 @@ class FlatBuffer:
                 view.copy_(p.data)
                 p.data = view
                 self.gviews.append(self.flat_g[o:o + p.numel()].as_strided(p.shape, p.data.stride()))
+                # producers that can write a gradient in place (the fused Bottleneck's weight gradients) take this
+                # view as their output: the optimizer's gather then has nothing to copy for that parameter
+                p._scn_flat_grad = self.gviews[-1]
                 p.grad = None
 
     def zero_grad(self):
