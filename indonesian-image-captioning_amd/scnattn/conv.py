@@ -414,7 +414,20 @@ class _BottleneckFn(torch.autograd.Function):
                 (dgbd[0] if need[13] else None) if dgbd is not None else None)
 
 
-C_DRIVER = os.environ.get("SCNATTN_BLOCK_DRIVER", "1") != "0"   # identity blocks: one C call forward, one backward
+# Identity blocks through the whole-block C drivers (one call forward, one backward).  Measured on one MI355X: the step is
+# GPU-bound either way and the per-call path with its per-shape conv2 autotune is 1.5 % faster (789-800 vs 777-782
+# images/s); with data-parallel hooks taking host time in the autograd thread the drivers win (664 vs 650 at one rank with
+# --force-dist).  "auto" (default): drivers when torch.distributed runs more than one rank.
+_drv = os.environ.get("SCNATTN_BLOCK_DRIVER", "auto")
+C_DRIVER = None if _drv == "auto" else (_drv != "0")
+
+
+def _use_c_driver():
+    if C_DRIVER is not None:
+        return C_DRIVER
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
 _block_sizes = {}
 _scratch_rings = {}
 
@@ -574,7 +587,7 @@ def bottleneck(mod, x):
         wd = gd = bd = None
         # (64-channel 3x3 convolutions -- layer1 -- are the one shape where MIOpen's kernel wins clearly: those blocks
         #  keep the per-call path with its autotuned conv2)
-        if C_DRIVER and mod.stride == 1 and mod.conv2.weight.is_contiguous(memory_format=torch.channels_last) \
+        if _use_c_driver() and mod.stride == 1 and mod.conv2.weight.is_contiguous(memory_format=torch.channels_last) \
                 and mod.conv1.weight.shape[1] == 4 * mod.conv1.weight.shape[0] and mod.conv1.weight.shape[0] >= 128:
             return _BlockFnC.apply(mod, x, mod.conv1.weight, mod.bn1.weight, mod.bn1.bias, mod.conv2.weight,
                                    mod.bn2.weight, mod.bn2.bias, mod.conv3.weight, mod.bn3.weight, mod.bn3.bias)

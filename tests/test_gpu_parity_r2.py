@@ -537,7 +537,7 @@ def test_fused_bottleneck_vs_fp64(dev, name, inplanes, planes, stride, H, small,
         finally:
             SC.ENABLED = True
             SC.CONV3 = "auto"
-            SC.C_DRIVER = True
+            SC.C_DRIVER = None
         res[fused] = (y.detach(), xg.grad.detach(), {k: p.grad.detach() for k, p in g.named_parameters()},
                       {k: b.detach().clone() for k, b in g.named_buffers()})
     rep = []
