@@ -410,6 +410,8 @@ def main():
             out["config"]["trunk"] = ("fused Bottleneck: every 1x1 convolution (fwd, dgrad, wgrad) on csrc/cgemm.hip with "
                                       "BatchNorm prologues/epilogues; 3x3 fwd/dgrad per shape by autotune (SCNATTN_CONV3=%s): "
                                       % _conv.CONV3) + ", ".join("%s%s=%s" % (k[0], list(k[1:]), v) for k, v in sorted(_conv.conv3_choices().items()))
+            out["config"]["side_stream"] = "; ".join("weight gradients on a second HIP stream, found concurrent with the main "
+                                                     "stream by experiment (%s)" % sd.probe for sd in _conv._sides.values()) or None
         if elapsed_di is not None:
             out["drop_in_call"] = {"value": round(world * args.batch * args.steps / elapsed_di, 3), "unit": "images/sec",
                                    "ms_per_step": round(1e3 * elapsed_di / args.steps, 3),

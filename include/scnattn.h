@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SCNATTN_VERSION 102 /* 0.1.2: scnattn_cgemm / scnattn_conv1x1_* / scnattn_bn_finalize */
+#define SCNATTN_VERSION 103 /* 0.1.3: + scnattn_dp_comm_set_stream */
 
 int scnattn_version(void);
 const char* scnattn_last_error(void);
@@ -355,6 +355,9 @@ int scnattn_bn_bwd_finalize(void* stream, int C, int nchunk, const float* partia
  *           on compute_stream so far has run; returns at once;
  *   scnattn_dp_comm_finish(comm, compute_stream): compute_stream waits for every bucket handed over so far
  *           (call before the optimizer reads the gradients; the 1/world scale is folded into scnattn_clamp_adam);
+ *   scnattn_dp_comm_set_stream(comm, stream): optional -- reduce on a caller-owned stream instead of the library's
+ *     (HIP maps streams onto a few hardware queues; a host that has probed which of its streams really run beside
+ *     the compute stream hands that one over; NULL returns to the library's own stream);
  *   scnattn_dp_comm_destroy(comm).
  * Return codes >= 1000 are 1000 + ncclResult_t. */
 typedef struct scnattn_dp_comm scnattn_dp_comm;
@@ -362,6 +365,7 @@ int scnattn_dp_unique_id(char out[128]);
 int scnattn_dp_comm_create(const char id[128], int world, int rank, scnattn_dp_comm** out);
 int scnattn_dp_comm_allreduce_bucket(scnattn_dp_comm* comm, void* compute_stream, float* buf, long n);
 int scnattn_dp_comm_finish(scnattn_dp_comm* comm, void* compute_stream);
+int scnattn_dp_comm_set_stream(scnattn_dp_comm* comm, void* stream);
 int scnattn_dp_comm_world(const scnattn_dp_comm* comm);
 int scnattn_dp_comm_destroy(scnattn_dp_comm* comm);
 

@@ -82,7 +82,8 @@ int load_rccl() {
 
 struct scnattn_dp_comm {
     void* comm = nullptr;
-    hipStream_t stream = nullptr;     // communication stream (owned)
+    hipStream_t stream = nullptr;     // communication stream in use
+    hipStream_t own = nullptr;        // the library's own communication stream
     hipEvent_t ready = nullptr;       // recorded on the compute stream before a bucket is reduced
     hipEvent_t done = nullptr;        // recorded on the communication stream after the last bucket
     int world = 1, rank = 0, device = 0;
@@ -117,7 +118,8 @@ int scnattn_dp_comm_create(const char id[128], int world, int rank, scnattn_dp_c
         delete c;
         return 1000 + rc;
     }
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    hipError_t e = hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking);
+    c->stream = c->own;
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ready, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done, hipEventDisableTiming);
     if (e != hipSuccess) {
@@ -150,12 +152,20 @@ int scnattn_dp_comm_finish(scnattn_dp_comm* c, void* compute_stream) {
     return 0;
 }
 
+int scnattn_dp_comm_set_stream(scnattn_dp_comm* c, void* stream) {
+    SCN_ARG(c, "dp_comm_set_stream: NULL");
+    SCN_ARG(c->buckets == 0, "dp_comm_set_stream: buckets in flight (call scnattn_dp_comm_finish first)");
+    c->stream = stream ? reinterpret_cast<hipStream_t>(stream) : c->own;
+    return 0;
+}
+
 int scnattn_dp_comm_world(const scnattn_dp_comm* c) { return c ? c->world : 0; }
 
 int scnattn_dp_comm_destroy(scnattn_dp_comm* c) {
     if (!c) return 0;
     (void)hipStreamSynchronize(c->stream);
     if (c->comm) g_rccl.CommDestroy(c->comm);
+    c->stream = c->own;
     if (c->ready) (void)hipEventDestroy(c->ready);
     if (c->done) (void)hipEventDestroy(c->done);
     if (c->stream) (void)hipStreamDestroy(c->stream);

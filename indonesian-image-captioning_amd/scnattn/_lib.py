@@ -122,6 +122,7 @@ _SIGS = {
     "scnattn_dp_comm_create": ([C.c_char_p, i32, i32, C.POINTER(vp)], i32),
     "scnattn_dp_comm_allreduce_bucket": ([vp, vp, vp, i64], i32),
     "scnattn_dp_comm_finish": ([vp, vp], i32),
+    "scnattn_dp_comm_set_stream": ([vp, vp], i32),
     "scnattn_dp_comm_world": ([vp], i32),
     "scnattn_dp_comm_destroy": ([vp], i32),
     "scnattn_clamp_adam": ([vp, i64, vp, vp, vp, vp, f64, f64, f64, f64, i32, f64, f64], i32),

@@ -85,6 +85,43 @@ def conv3_choices():
     return {k: ("hip" if v else "miopen") for k, v in _c3_choice.items()}
 
 
+def _concurrent_stream(dev, attempts=8, beside=()):
+    """A stream whose kernels really run beside the current stream's.  HIP multiplexes its streams onto a few hardware
+    queues (4 by default); two streams that land on the same queue are serialised, and which ones collide depends on
+    how many streams the process created before (RCCL's, the allocator's, another module's).  Measured on MI355X: with
+    a torch.distributed group initialised first, the side stream shared the main stream's queue and the step lost all
+    of its overlap (47.8 instead of 40.6 ms).  So the stream is chosen by experiment: a spin kernel occupies the main
+    stream, a tiny kernel is enqueued on the candidate; if the tiny kernel finishes while the spin kernel is still
+    running, the two are concurrent.  `beside`: further streams the new one must not collide with either."""
+    main = torch.cuda.current_stream(dev)
+    probe = torch.zeros(64, device=dev)
+    tried = []
+    with torch.cuda.device(dev):
+        for i in range(attempts):
+            cand = torch.cuda.Stream(device=dev)
+            tried.append(cand)                 # keep it referenced: the pool hands out a different stream next time
+            with torch.cuda.stream(cand):
+                probe.add_(1.0)                # code object / allocator warm-up on the candidate
+            torch.cuda.synchronize(dev)
+            busy = []
+            for st in (main,) + tuple(beside):
+                with torch.cuda.stream(st):
+                    torch.cuda._sleep(40_000_000)      # a few milliseconds of spinning
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    busy.append(ev)
+            with torch.cuda.stream(cand):
+                probe.add_(1.0)
+                done_side = torch.cuda.Event()
+                done_side.record(cand)
+            done_side.synchronize()
+            concurrent = not any(ev.query() for ev in busy)
+            torch.cuda.synchronize(dev)
+            if concurrent:
+                return cand, "attempt %d of %d" % (i + 1, attempts)
+    return tried[0], "no concurrent stream found in %d attempts" % attempts
+
+
 class _Side:
     """Weight gradients off the critical path.  In a block's backward pass the three (four) weight-gradient products
     feed nothing until the optimizer step, while the d-input chain is strictly serial and every kernel in it has a
@@ -94,7 +131,7 @@ class _Side:
     side stream touches are tagged with record_stream so the caching allocator keeps them alive."""
 
     def __init__(self, dev):
-        self.stream = torch.cuda.Stream(device=dev)
+        self.stream, self.probe = _concurrent_stream(dev)
         self.ws = torch.empty(16 << 20, device=dev, dtype=torch.float32)
         self.pending = None
 

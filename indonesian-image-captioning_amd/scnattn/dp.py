@@ -42,6 +42,12 @@ class CabiComm:
         handle = C.c_void_p()
         _lib.check(self.h.scnattn_dp_comm_create(buf, world, rank, C.byref(handle)), "scnattn_dp_comm_create")
         self.handle, self.world, self.device = handle, world, device
+        # reduce on a stream that is known to run beside both the compute stream and the weight-gradient stream
+        # (scnattn/conv.py::_concurrent_stream: HIP streams share a handful of hardware queues)
+        from . import conv as _conv
+        self.stream, self.probe = _conv._concurrent_stream(device, beside=(_conv._side(device).stream,))
+        _lib.check(self.h.scnattn_dp_comm_set_stream(handle, C.c_void_p(self.stream.cuda_stream)),
+                   "scnattn_dp_comm_set_stream")
 
     @classmethod
     def get(cls, device):
