@@ -451,11 +451,12 @@ class _BottleneckFn(torch.autograd.Function):
                 (dgbd[0] if need[13] else None) if dgbd is not None else None)
 
 
-# Identity blocks through the whole-block C drivers (one call forward, one backward).  Measured on one MI355X: the step is
-# GPU-bound either way and the per-call path with its per-shape conv2 autotune is 1.5 % faster (789-800 vs 777-782
-# images/s); with data-parallel hooks taking host time in the autograd thread the drivers win (664 vs 650 at one rank with
-# --force-dist).  "auto" (default): drivers when torch.distributed runs more than one rank.
-_drv = os.environ.get("SCNATTN_BLOCK_DRIVER", "auto")
+# Identity blocks through the whole-block C drivers (one call forward, one backward): SCNATTN_BLOCK_DRIVER=1.  Measured on
+# one MI355X: the step is GPU-bound either way; the per-call path with its per-shape conv2 autotune is 1.5 % faster on a
+# single GPU (789-800 vs 777-782 images/s) and equal within noise under the data-parallel hooks (--force-dist, one rank:
+# 760 / 770 vs 766 / 769 images/s with the torch / C-ABI RCCL back end).  So the drivers are an entry point for hosts that
+# cannot afford ~40 Python-level calls per block (include/scnattn.h: scnattn_block_*), not the default of this one.
+_drv = os.environ.get("SCNATTN_BLOCK_DRIVER", "0")
 C_DRIVER = None if _drv == "auto" else (_drv != "0")
 
 
