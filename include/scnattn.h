@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SCNATTN_VERSION 103 /* 0.1.3: + scnattn_dp_comm_set_stream */
+#define SCNATTN_VERSION 104 /* 0.1.4: + scnattn_seq_bwd_streams, scnattn_dp_comm_set_stream */
 
 int scnattn_version(void);
 const char* scnattn_last_error(void);
@@ -136,6 +136,17 @@ int scnattn_seq_bwd(void* stream, const scnattn_dims* d, const scnattn_params* w
                     const float* drop_mask, const float* saved, float* scratch, const float* dpreds,
                     const float* dalphas, const scnattn_params* g, float* denc, float* dtags,
                     const scnattn_pool* pool);
+/* The same with the weight gradients on a second stream.  Nothing needs d loss / d weight before the optimizer step,
+ * while denc heads the encoder's whole backward pass (trains/attention_scn.py:238-240 runs them as one autograd
+ * sweep): `wgrad_stream` carries d fc.weight beside the reverse recurrence and the post-loop weight-gradient GEMMs
+ * beside whatever the caller enqueues next on `stream`.  Event-ordered inside; on return `stream` holds denc / dtags
+ * and does NOT wait for `wgrad_stream`: the caller joins it before reading `g`, and keeps saved / scratch / dpreds /
+ * enc / tags alive until then.  wgrad_stream == NULL or == stream: identical to scnattn_seq_bwd. */
+int scnattn_seq_bwd_streams(void* stream, void* wgrad_stream, const scnattn_dims* d, const scnattn_params* w,
+                            const float* enc, const float* tags, const int64_t* caps, const int32_t* dl_dev,
+                            const int32_t* bt_host, const float* drop_mask, const float* saved, float* scratch,
+                            const float* dpreds, const float* dalphas, const scnattn_params* g, float* denc,
+                            float* dtags, const scnattn_pool* pool);
 
 /* ---- primitives (each = one kernel launch); used by the stand-alone modules and the tests ------- */
 /* C = alpha*op(A).op(B) + beta*C + bias[n]; rows with rowmask[m]==0 written as 0.  Replaces the

@@ -31,10 +31,10 @@ int seq_workspace(const scnattn_dims* d, const scnattn_pool* pool, size_t* saved
 int seq_fwd(hipStream_t st, const scnattn_dims* d, const scnattn_params* w, const float* enc, const float* tags,
             const int64_t* caps, const int32_t* dl_dev, const int32_t* bt, const float* drop_mask, float* saved,
             float* scratch, float* preds, float* alphas, const scnattn_pool* pool);
-int seq_bwd(hipStream_t st, const scnattn_dims* d, const scnattn_params* w, const float* enc, const float* tags,
-            const int64_t* caps, const int32_t* dl_dev, const int32_t* bt, const float* drop_mask, const float* saved,
-            float* scratch, const float* dpreds, const float* dalphas, const scnattn_params* g, float* denc,
-            float* dtags, const scnattn_pool* pool);
+int seq_bwd(hipStream_t st, hipStream_t wst, const scnattn_dims* d, const scnattn_params* w, const float* enc,
+            const float* tags, const int64_t* caps, const int32_t* dl_dev, const int32_t* bt, const float* drop_mask,
+            const float* saved, float* scratch, const float* dpreds, const float* dalphas, const scnattn_params* g,
+            float* denc, float* dtags, const scnattn_pool* pool);
 
 }  // namespace scn
 
@@ -101,8 +101,17 @@ int scnattn_seq_bwd(void* stream, const scnattn_dims* d, const scnattn_params* w
                     const float* drop_mask, const float* saved, float* scratch, const float* dpreds,
                     const float* dalphas, const scnattn_params* g, float* denc, float* dtags,
                     const scnattn_pool* pool) {
-    return seq_bwd(ST(stream), d, w, enc, tags, caps, dl_dev, bt_host, drop_mask, saved, scratch, dpreds, dalphas, g,
-                   denc, dtags, pool);
+    return seq_bwd(ST(stream), nullptr, d, w, enc, tags, caps, dl_dev, bt_host, drop_mask, saved, scratch, dpreds,
+                   dalphas, g, denc, dtags, pool);
+}
+
+int scnattn_seq_bwd_streams(void* stream, void* wgrad_stream, const scnattn_dims* d, const scnattn_params* w,
+                            const float* enc, const float* tags, const int64_t* caps, const int32_t* dl_dev,
+                            const int32_t* bt_host, const float* drop_mask, const float* saved, float* scratch,
+                            const float* dpreds, const float* dalphas, const scnattn_params* g, float* denc,
+                            float* dtags, const scnattn_pool* pool) {
+    return seq_bwd(ST(stream), ST(wgrad_stream), d, w, enc, tags, caps, dl_dev, bt_host, drop_mask, saved, scratch,
+                   dpreds, dalphas, g, denc, dtags, pool);
 }
 
 int scnattn_sgemm(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A,

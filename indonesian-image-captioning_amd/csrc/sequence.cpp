@@ -101,7 +101,7 @@ struct FwdScratch {
 struct BwdScratch {
     float *WDb, *WaTz, *WcatT, *dHd_bm, *dhfc_tm, *dr_all, *dpx_all, *dcat_all, *dawe_all, *de_all, *dalpha, *dc,
         *dqx_acc, *dqh_acc, *sDb, *sZ, *sH, *datt1, *dwpart, *dwtmp, *demb_tm, *dmean, *dh0, *mx_all, *gws, *present,
-        *dalphaq, *dy;
+        *dalphaq, *dy, *gws2;
 };
 
 inline size_t sz(long a, long b = 1, long c = 1, long d = 1) { return (size_t)a * b * c * d; }
@@ -182,6 +182,7 @@ size_t carve_bwd(const scnattn_dims& d, int Q, float* base, BwdScratch& s) {
     s.gws = c.take(GEMM_WS_FLOATS);
     s.dalphaq = (d.has_att && Q > 0) ? c.take(sz(B, Q)) : nullptr;
     s.dy = (d.has_att && Q > 0) ? c.take(sz(B, Q, A)) : nullptr;
+    s.gws2 = c.take(GEMM_WS_FLOATS);      // split-K partials of the weight-gradient stream
     return c.off * sizeof(float);
 }
 
@@ -461,10 +462,15 @@ int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
     return 0;
 }
 
-int seq_bwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, const float* enc, const float* tags,
-            const int64_t* caps, const int32_t* dl_dev, const int32_t* bt, const float* drop_mask, const float* saved,
-            float* scratch, const float* dpreds, const float* dalphas, const scnattn_params* g, float* denc,
-            float* dtags, const scnattn_pool* pool) {
+// `wst`: optional second stream for the weight gradients.  Nothing downstream of this call needs d loss / d weight
+// before the optimizer step, while d encoder_out heads the whole encoder backward pass: with `wst` the fc weight
+// gradient runs beside the (latency-bound) reverse recurrence and the post-loop weight-gradient GEMMs beside whatever
+// the caller enqueues next on `st`.  Ordering is by events: `wst` waits for what it reads, `st` never waits for `wst`
+// -- the CALLER joins `wst` before it reads `g`.  NULL (or == st): everything in order on `st`.
+int seq_bwd(hipStream_t st, hipStream_t wst, const scnattn_dims* dp, const scnattn_params* w, const float* enc,
+            const float* tags, const int64_t* caps, const int32_t* dl_dev, const int32_t* bt, const float* drop_mask,
+            const float* saved, float* scratch, const float* dpreds, const float* dalphas, const scnattn_params* g,
+            float* denc, float* dtags, const scnattn_pool* pool) {
     SCN_TRY(check_dims(dp));
     SCN_TRY(check_bt(dp, bt));
     const scnattn_dims& d = *dp;
@@ -480,15 +486,30 @@ int seq_bwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
     BwdScratch k;
     carve_saved(d, Q, const_cast<float*>(saved), s);
     carve_bwd(d, Q, scratch, k);
+    const bool two = wst && wst != st;
+    hipStream_t ws = two ? wst : st;            // stream of the weight gradients
+    float* wgws = two ? k.gws2 : k.gws;         // ... and its split-K workspace
+    // ws_after_main(): everything enqueued on `st` so far happens-before what is enqueued on `ws` next
+    auto ws_after_main = [&]() -> int {
+        if (!two) return 0;
+        hipEvent_t e = nullptr;
+        SCN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        hipError_t r = hipEventRecord(e, st);
+        if (r == hipSuccess) r = hipStreamWaitEvent(ws, e, 0);
+        (void)hipEventDestroy(e);               // released once the wait has been satisfied
+        SCN_HIP(r);
+        return 0;
+    };
 
     // ---- fc / dropout ----------------------------------------------------------------------------
+    SCN_TRY(ws_after_main());
+    if (g->fc_weight)
+        SCN_TRY(sgemm_ws(ws, true, false, V, D, B * T, 1.f, dpreds, V, s.Hd_bm, D, 0.f, g->fc_weight, D, nullptr, nullptr,
+                      1, 0, 0, 0, wgws, GEMM_WS_FLOATS));
+    if (g->fc_bias)  // only rows that were decoded carry the bias
+        SCN_TRY(colsum_masked(ws, B * T, V, dpreds, V, s.rowmask, g->fc_bias, 0.f));
     SCN_TRY(sgemm_ws(st, false, false, B * T, D, V, 1.f, dpreds, V, w->fc_weight, D, 0.f, k.dHd_bm, D, nullptr, nullptr, 1,
                   0, 0, 0, k.gws, GEMM_WS_FLOATS));
-    if (g->fc_weight)
-        SCN_TRY(sgemm_ws(st, true, false, V, D, B * T, 1.f, dpreds, V, s.Hd_bm, D, 0.f, g->fc_weight, D, nullptr, nullptr,
-                      1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
-    if (g->fc_bias)  // only rows that were decoded carry the bias
-        SCN_TRY(colsum_masked(st, B * T, V, dpreds, V, s.rowmask, g->fc_bias, 0.f));
     SCN_TRY(hidden_from_bm(st, B, T, D, dl_dev, k.dHd_bm, drop_mask, k.dhfc_tm));
 
     // ---- transposed weight layouts for the backward contractions ------------------------------------
@@ -570,58 +591,107 @@ int seq_bwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
     }));
     prof_end(st, ev0, 1, T);
 
-    // ---- weight gradients: one GEMM per weight over the stacked (t,b) rows ---------------------------
-    if (g->decode_step_weight_ia) {
-        SCN_TRY(sgemm_ws(st, true, false, M, F4, TB, 1.f, s.emb_tm, M, k.dpx_all, F4, 0.f, g->decode_step_weight_ia, F4,
-                      nullptr, nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
-        if (d.has_att)
-            SCN_TRY(sgemm_ws(st, true, false, E, F4, TB, 1.f, s.z_all, E, k.dpx_all, F4, 0.f,
-                          g->decode_step_weight_ia + (long)M * F4, F4, nullptr, nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
-    }
-    if (g->embedding_weight) {
-        SCN_TRY(sgemm_ws(st, false, true, TB, M, F4, 1.f, k.dpx_all, F4, w->decode_step_weight_ia, F4, 0.f, k.demb_tm, M,
-                      nullptr, nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
-        SCN_TRY(scatter_add_rows_tm(st, B, T, d.L, M, (const long long*)caps, dl_dev, k.demb_tm, V,
-                                    g->embedding_weight, reinterpret_cast<int*>(k.present)));
-    }
-    if (g->decode_step_weight_ic) {
-        SCN_TRY(mul_bcast(st, T, B, F4, s.pa_all, s.qx, k.mx_all));
-        SCN_TRY(sgemm_ws(st, true, false, D, F, TB, 1.f, k.dr_all, 4 * D, k.mx_all, F4, 0.f, g->decode_step_weight_ic, F4,
-                      nullptr, nullptr, 4, D, F, F, k.gws, GEMM_WS_FLOATS));
-    }
-    if (g->decode_step_weight_hc) {
-        SCN_TRY(mul_bcast(st, T, B, F4, s.ph_all, s.qh, k.mx_all));
-        SCN_TRY(sgemm_ws(st, true, false, D, F, TB, 1.f, k.dr_all, 4 * D, k.mx_all, F4, 0.f, g->decode_step_weight_hc, F4,
-                      nullptr, nullptr, 4, D, F, F, k.gws, GEMM_WS_FLOATS));
-    }
-    if (g->decode_step_weight_ha)
-        SCN_TRY(sgemm_ws(st, true, false, D, F4, TB, 1.f, s.Hs, D, k.dcat_all, NC, 0.f, g->decode_step_weight_ha, F4,
-                      nullptr, nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
-    if (g->decode_step_weight_ib)
-        SCN_TRY(sgemm_ws(st, true, false, d.S, F4, B, 1.f, tags, d.S, k.dqx_acc, F4, 0.f, g->decode_step_weight_ib, F4,
-                      nullptr, nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
-    if (g->decode_step_weight_hb)
-        SCN_TRY(sgemm_ws(st, true, false, d.S, F4, B, 1.f, tags, d.S, k.dqh_acc, F4, 0.f, g->decode_step_weight_hb, F4,
-                      nullptr, nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
+    // ---- after the loop: two strands ------------------------------------------------------------------
+    // (1) weight gradients, one GEMM per weight over the stacked (t,b) rows: stream `ws`, off the critical path;
+    // (2) d tags, d att1 -> d encoder_out: stream `st`, heads the encoder's backward pass.
+    // The events are recorded where the inputs of (1) come into being; with two streams its launches are enqueued
+    // LAST, so that the host reaches strand (2) first.
+    hipEvent_t ev_loop = nullptr, ev_att = nullptr;
+    auto mark = [&](hipEvent_t* e) -> int {
+        if (!two) return 0;
+        SCN_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        SCN_HIP(hipEventRecord(*e, st));
+        return 0;
+    };
+    auto ws_wait = [&](hipEvent_t* e) -> int {
+        if (!two || !*e) return 0;
+        const hipError_t r = hipStreamWaitEvent(ws, *e, 0);
+        (void)hipEventDestroy(*e);
+        *e = nullptr;
+        SCN_HIP(r);
+        return 0;
+    };
+    auto wgrad_loop = [&]() -> int {      // everything whose operands the reverse recurrence produced
+        SCN_TRY(ws_wait(&ev_loop));
+        if (g->decode_step_weight_ia) {
+            SCN_TRY(sgemm_ws(ws, true, false, M, F4, TB, 1.f, s.emb_tm, M, k.dpx_all, F4, 0.f, g->decode_step_weight_ia, F4,
+                          nullptr, nullptr, 1, 0, 0, 0, wgws, GEMM_WS_FLOATS));
+            if (d.has_att)
+                SCN_TRY(sgemm_ws(ws, true, false, E, F4, TB, 1.f, s.z_all, E, k.dpx_all, F4, 0.f,
+                              g->decode_step_weight_ia + (long)M * F4, F4, nullptr, nullptr, 1, 0, 0, 0, wgws, GEMM_WS_FLOATS));
+        }
+        if (g->embedding_weight) {
+            SCN_TRY(sgemm_ws(ws, false, true, TB, M, F4, 1.f, k.dpx_all, F4, w->decode_step_weight_ia, F4, 0.f, k.demb_tm, M,
+                          nullptr, nullptr, 1, 0, 0, 0, wgws, GEMM_WS_FLOATS));
+            SCN_TRY(scatter_add_rows_tm(ws, B, T, d.L, M, (const long long*)caps, dl_dev, k.demb_tm, V,
+                                        g->embedding_weight, reinterpret_cast<int*>(k.present)));
+        }
+        if (g->decode_step_weight_ic) {
+            SCN_TRY(mul_bcast(ws, T, B, F4, s.pa_all, s.qx, k.mx_all));
+            SCN_TRY(sgemm_ws(ws, true, false, D, F, TB, 1.f, k.dr_all, 4 * D, k.mx_all, F4, 0.f, g->decode_step_weight_ic, F4,
+                          nullptr, nullptr, 4, D, F, F, wgws, GEMM_WS_FLOATS));
+        }
+        if (g->decode_step_weight_hc) {
+            SCN_TRY(mul_bcast(ws, T, B, F4, s.ph_all, s.qh, k.mx_all));
+            SCN_TRY(sgemm_ws(ws, true, false, D, F, TB, 1.f, k.dr_all, 4 * D, k.mx_all, F4, 0.f, g->decode_step_weight_hc, F4,
+                          nullptr, nullptr, 4, D, F, F, wgws, GEMM_WS_FLOATS));
+        }
+        if (g->decode_step_weight_ha)
+            SCN_TRY(sgemm_ws(ws, true, false, D, F4, TB, 1.f, s.Hs, D, k.dcat_all, NC, 0.f, g->decode_step_weight_ha, F4,
+                          nullptr, nullptr, 1, 0, 0, 0, wgws, GEMM_WS_FLOATS));
+        if (g->decode_step_weight_ib)
+            SCN_TRY(sgemm_ws(ws, true, false, d.S, F4, B, 1.f, tags, d.S, k.dqx_acc, F4, 0.f, g->decode_step_weight_ib, F4,
+                          nullptr, nullptr, 1, 0, 0, 0, wgws, GEMM_WS_FLOATS));
+        if (g->decode_step_weight_hb)
+            SCN_TRY(sgemm_ws(ws, true, false, d.S, F4, B, 1.f, tags, d.S, k.dqh_acc, F4, 0.f, g->decode_step_weight_hb, F4,
+                          nullptr, nullptr, 1, 0, 0, 0, wgws, GEMM_WS_FLOATS));
+        if (g->decode_step_bias_ih) SCN_TRY(colsum(ws, TB, 4 * D, k.dr_all, 4 * D, g->decode_step_bias_ih, 0.f));
+        if (g->decode_step_bias_hh) SCN_TRY(colsum(ws, TB, 4 * D, k.dr_all, 4 * D, g->decode_step_bias_hh, 0.f));
+        if (d.has_att) {
+            if (g->f_beta_weight)
+                SCN_TRY(sgemm_ws(ws, true, false, E, D, TB, 1.f, k.dcat_all + F4, NC, s.Hs, D, 0.f, g->f_beta_weight, D,
+                              nullptr, nullptr, 1, 0, 0, 0, wgws, GEMM_WS_FLOATS));
+            if (g->f_beta_bias) SCN_TRY(colsum(ws, TB, E, k.dcat_all + F4, NC, g->f_beta_bias, 0.f));
+            if (g->attention_decoder_att_weight)
+                SCN_TRY(sgemm_ws(ws, true, false, A, D, TB, 1.f, k.dcat_all + F4 + E, NC, s.Hs, D, 0.f,
+                              g->attention_decoder_att_weight, D, nullptr, nullptr, 1, 0, 0, 0, wgws, GEMM_WS_FLOATS));
+            if (g->attention_decoder_att_bias)
+                SCN_TRY(colsum(ws, TB, A, k.dcat_all + F4 + E, NC, g->attention_decoder_att_bias, 0.f));
+        }
+        if (g->init_h_weight)
+            SCN_TRY(sgemm_ws(ws, true, false, D, E, B, 1.f, k.dh0, D, s.mean_enc, E, 0.f, g->init_h_weight, E, nullptr,
+                          nullptr, 1, 0, 0, 0, wgws, GEMM_WS_FLOATS));
+        if (g->init_h_bias) SCN_TRY(colsum(ws, B, D, k.dh0, D, g->init_h_bias, 0.f));
+        if (g->init_c_weight)
+            SCN_TRY(sgemm_ws(ws, true, false, D, E, B, 1.f, k.dc, D, s.mean_enc, E, 0.f, g->init_c_weight, E, nullptr, nullptr,
+                          1, 0, 0, 0, wgws, GEMM_WS_FLOATS));
+        if (g->init_c_bias) SCN_TRY(colsum(ws, B, D, k.dc, D, g->init_c_bias, 0.f));
+        return 0;
+    };
+    auto wgrad_att = [&]() -> int {       // d encoder_att: needs d att1 (/ d y)
+        SCN_TRY(ws_wait(&ev_att));
+        if (!d.has_att) return 0;
+        if (g->attention_encoder_att_weight) {
+            if (Q > 0)
+                SCN_TRY(sgemm_ws(ws, true, false, A, E, B * Q, 1.f, k.dy, A, enc, E, 0.f, g->attention_encoder_att_weight,
+                              E, nullptr, nullptr, 1, 0, 0, 0, wgws, GEMM_WS_FLOATS));
+            else
+                SCN_TRY(sgemm_ws(ws, true, false, A, E, B * P, 1.f, k.datt1, A, enc, E, 0.f,
+                              g->attention_encoder_att_weight, E, nullptr, nullptr, 1, 0, 0, 0, wgws, GEMM_WS_FLOATS));
+        }
+        if (g->attention_encoder_att_bias)
+            SCN_TRY(colsum(ws, B * P, A, k.datt1, A, g->attention_encoder_att_bias, 0.f));
+        return 0;
+    };
+    SCN_TRY(mark(&ev_loop));
+    if (!two) SCN_TRY(wgrad_loop());
     if (dtags) {
         SCN_TRY(sgemm_ws(st, false, true, B, d.S, F4, 1.f, k.dqx_acc, F4, w->decode_step_weight_ib, F4, 0.f, dtags, d.S,
                       nullptr, nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
         SCN_TRY(sgemm_ws(st, false, true, B, d.S, F4, 1.f, k.dqh_acc, F4, w->decode_step_weight_hb, F4, 1.f, dtags, d.S,
                       nullptr, nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
     }
-    if (g->decode_step_bias_ih) SCN_TRY(colsum(st, TB, 4 * D, k.dr_all, 4 * D, g->decode_step_bias_ih, 0.f));
-    if (g->decode_step_bias_hh) SCN_TRY(colsum(st, TB, 4 * D, k.dr_all, 4 * D, g->decode_step_bias_hh, 0.f));
-
     if (d.has_att) {
-        if (g->f_beta_weight)
-            SCN_TRY(sgemm_ws(st, true, false, E, D, TB, 1.f, k.dcat_all + F4, NC, s.Hs, D, 0.f, g->f_beta_weight, D,
-                          nullptr, nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
-        if (g->f_beta_bias) SCN_TRY(colsum(st, TB, E, k.dcat_all + F4, NC, g->f_beta_bias, 0.f));
-        if (g->attention_decoder_att_weight)
-            SCN_TRY(sgemm_ws(st, true, false, A, D, TB, 1.f, k.dcat_all + F4 + E, NC, s.Hs, D, 0.f,
-                          g->attention_decoder_att_weight, D, nullptr, nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
-        if (g->attention_decoder_att_bias)
-            SCN_TRY(colsum(st, TB, A, k.dcat_all + F4 + E, NC, g->attention_decoder_att_bias, 0.f));
         int nblk = 0;
         SCN_TRY(attn_datt1_post(st, B, P, A, T, dl_dev, s.att1, s.att2_all, k.de_all, w->attention_full_att_weight,
                                 k.datt1, k.dwpart, &nblk));
@@ -631,27 +701,9 @@ int seq_bwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
         if (g->attention_full_att_bias) SCN_TRY(copy2d(st, 1, 1, k.dwtmp + A, 1, g->attention_full_att_bias, 1));
         if (Q > 0 && (g->attention_encoder_att_weight || denc))
             SCN_TRY(pool_transpose(st, B, P, A, pd, k.datt1, k.dy));      // d y = pool^T (d att1): [B*Q][A]
-        if (g->attention_encoder_att_weight) {
-            if (Q > 0)
-                SCN_TRY(sgemm_ws(st, true, false, A, E, B * Q, 1.f, k.dy, A, enc, E, 0.f, g->attention_encoder_att_weight,
-                              E, nullptr, nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
-            else
-                SCN_TRY(sgemm_ws(st, true, false, A, E, B * P, 1.f, k.datt1, A, enc, E, 0.f,
-                              g->attention_encoder_att_weight, E, nullptr, nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
-        }
-        if (g->attention_encoder_att_bias)
-            SCN_TRY(colsum(st, B * P, A, k.datt1, A, g->attention_encoder_att_bias, 0.f));
     }
-
-    // ---- initial state (attention_scn.py:82-93) -----------------------------------------------------
-    if (g->init_h_weight)
-        SCN_TRY(sgemm_ws(st, true, false, D, E, B, 1.f, k.dh0, D, s.mean_enc, E, 0.f, g->init_h_weight, E, nullptr,
-                      nullptr, 1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
-    if (g->init_h_bias) SCN_TRY(colsum(st, B, D, k.dh0, D, g->init_h_bias, 0.f));
-    if (g->init_c_weight)
-        SCN_TRY(sgemm_ws(st, true, false, D, E, B, 1.f, k.dc, D, s.mean_enc, E, 0.f, g->init_c_weight, E, nullptr, nullptr,
-                      1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
-    if (g->init_c_bias) SCN_TRY(colsum(st, B, D, k.dc, D, g->init_c_bias, 0.f));
+    SCN_TRY(mark(&ev_att));
+    if (!two) SCN_TRY(wgrad_att());
 
     // ---- d loss / d encoder_out (only when the encoder is fine-tuned) -------------------------------
     if (denc && Q > 0) {
@@ -684,6 +736,10 @@ int seq_bwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
         SCN_TRY(sgemm_ws(st, false, false, B, E, D, 1.f, k.dc, D, w->init_c_weight, E, 1.f, k.dmean, E, nullptr, nullptr,
                       1, 0, 0, 0, k.gws, GEMM_WS_FLOATS));
         SCN_TRY(add_bcast_rows(st, B, P, E, k.dmean, 1.f / (float)P, denc));
+    }
+    if (two) {
+        SCN_TRY(wgrad_loop());
+        SCN_TRY(wgrad_att());
     }
     return 0;
 }

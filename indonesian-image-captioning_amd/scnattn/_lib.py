@@ -73,6 +73,8 @@ _SIGS = {
                          C.POINTER(Pool)], i32),
     "scnattn_seq_bwd": ([vp, C.POINTER(Dims), C.POINTER(Params), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                          C.POINTER(Params), vp, vp, C.POINTER(Pool)], i32),
+    "scnattn_seq_bwd_streams": ([vp, vp, C.POINTER(Dims), C.POINTER(Params), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                 C.POINTER(Params), vp, vp, C.POINTER(Pool)], i32),
     "scnattn_sgemm": ([vp, i32, i32, i32, i32, i32, f32, vp, i64, vp, i64, f32, vp, i64, vp, vp, i32, i64, i64, i64], i32),
     "scnattn_sgemm_ws": ([vp, i32, i32, i32, i32, i32, f32, vp, i64, vp, i64, f32, vp, i64, vp, vp, i32, i64, i64, i64,
                           vp, i64], i32),

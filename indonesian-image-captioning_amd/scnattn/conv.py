@@ -134,6 +134,7 @@ class _Side:
         self.stream, self.probe = _concurrent_stream(dev)
         self.ws = torch.empty(16 << 20, device=dev, dtype=torch.float32)
         self.pending = None
+        self.join_task = -1
 
     def fork(self, main, *tensors):
         ev = torch.cuda.Event()
@@ -148,6 +149,17 @@ class _Side:
         ev = torch.cuda.Event()
         ev.record(self.stream)
         self.pending = ev
+        # Inside an autograd sweep: join at its end, so that `loss.backward()` keeps its contract -- every .grad is
+        # ready in stream order on the caller's stream, whatever optimizer / clipping code reads it next (the
+        # reference's own loop reads p.grad right after backward: utils/optimizer.py:1-11, trains/attention_scn.py:244-252).
+        task = torch._C._current_graph_task_id()
+        if task != -1 and task != self.join_task:
+            self.join_task = task
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+
+    def _end_of_backward(self):
+        self.join_task = -1
+        self.join()
 
     def join(self, main=None):
         if self.pending is not None:
@@ -163,6 +175,21 @@ def _side(dev):
     if sd is None:
         sd = _sides[dev] = _Side(dev)
     return sd
+
+
+def side_ok(*params):
+    """May the gradients of `params` be produced on the side stream?  Only while autograd merely STORES what backward
+    returns for them: a leaf whose .grad is None (AccumulateGrad keeps the tensor; no kernel touches it before the join
+    at the end of the sweep).  A non-leaf's gradient is consumed by the next backward node on the main stream at once,
+    an existing .grad is added to on the main stream at once."""
+    if not SIDE_WGRAD:
+        return False
+    for p in params:
+        if p is None:
+            continue
+        if not p.is_leaf or p.grad is not None:
+            return False
+    return True
 
 
 def join_side_streams():
@@ -344,7 +371,7 @@ class _BottleneckFn(torch.autograd.Function):
              "scnattn_bn_bwd")
         # ---- conv3: wgrad with a2 recomputed on load, dgrad with the bn2 mask / reduction epilogue ----------------
         main = torch.cuda.current_stream(dev)
-        side = _side(dev) if SIDE_WGRAD else None
+        side = _side(dev) if side_ok(w1, w2, w3, wd) else None
         dw3 = None
         if need[8]:
             dw3 = _grad_out(w3)
@@ -558,7 +585,7 @@ class _BlockFnC(torch.autograd.Function):
         dw1 = _grad_out(w1) if need[2] else None
         dw3 = _grad_out(w3) if need[8] else None
         gr = BlockGrads(None if dw1 is None else dw1.data_ptr(), None if dw3 is None else dw3.data_ptr())
-        side = _side(dev) if SIDE_WGRAD else None
+        side = _side(dev) if side_ok(w1, w2, w3) else None
         if side is not None:
             for t_ in (saved, x):
                 t_.record_stream(side.stream)

@@ -9,6 +9,7 @@ wrapper covers, by reference file:
   pool_permute     -> models/encoders/caption.py:41-43
 """
 import ctypes as C
+import os
 import threading
 
 import torch
@@ -147,6 +148,13 @@ def _workspace(nfloats, dev, fully_written):
     return ws
 
 
+# Weight gradients of the decoder on the side stream (scnattn_seq_bwd_streams).  Bit-identical (tested) but not faster
+# on one MI355X: 782-797 images/s with it, 793 without -- the GEMMs it moves off the main stream land beside an encoder
+# backward pass that already keeps the chip busy, and d fc.weight beside the reverse recurrence slows that loop by
+# ~1 us per step.  Opt-in.
+DECODER_SIDE_WGRAD = os.environ.get("SCNATTN_DECODER_SIDE_WGRAD", "0") != "0"
+
+
 class _DecoderSeq(torch.autograd.Function):
     @staticmethod
     def forward(ctx, meta, enc, tags, caps, dl_dev, drop_mask, *weights):
@@ -157,6 +165,7 @@ class _DecoderSeq(torch.autograd.Function):
         dev = enc.device
         enc, tags = f32c(enc), f32c(tags)
         caps = caps.contiguous()
+        params_in = weights                  # the caller's tensors (Parameters): backward looks at their .grad
         weights = tuple(None if w is None else f32c(w.detach()) for w in weights)
         drop_mask = f32c(drop_mask)
         sv, sc = C.c_size_t(), C.c_size_t()
@@ -175,6 +184,7 @@ class _DecoderSeq(torch.autograd.Function):
         call("scnattn_seq_fwd", stream_of(enc), C.byref(d), C.byref(w), ptr(enc), ptr(tags), ptr(caps), ptr(dl_dev),
              C.cast(bt, C.c_void_p), ptr(drop_mask), ptr(saved), ptr(scratch), ptr(preds), ptr(alphas), cpool)
         ctx.meta = (dims_t, tuple(bt_host), sc.value, pool)
+        ctx.params = params_in
         ctx.save_for_backward(enc, tags, caps, dl_dev, drop_mask, saved, *[x for x in weights if x is not None])
         ctx.wmask = tuple(x is not None for x in weights)
         if alphas is None:
@@ -207,9 +217,26 @@ class _DecoderSeq(torch.autograd.Function):
         dtags = torch.empty_like(tags) if need[2] else None
         bt = (C.c_int32 * d.T)(*bt_host)
         w, g = _params_struct(weights), _params_struct(grads)
-        call("scnattn_seq_bwd", stream_of(enc), C.byref(d), C.byref(w), ptr(enc), ptr(tags), ptr(caps), ptr(dl_dev),
-             C.cast(bt, C.c_void_p), ptr(drop_mask), ptr(saved), ptr(scratch), ptr(dpreds), ptr(dalphas),
-             C.byref(g), ptr(denc), ptr(dtags), cpool)
+        # Weight gradients on the side stream (scnattn/conv.py::_Side, shared with the trunk): d fc.weight runs beside
+        # the reverse recurrence, the post-loop weight-gradient GEMMs beside the encoder's backward pass that `denc`
+        # starts.  Safe only while autograd merely STORES the returned tensors (conv.side_ok); the stream is joined at
+        # the end of the autograd sweep (conv._Side.mark) or by whoever reads the gradients first (FlatBuffer.gather).
+        side = None
+        if DECODER_SIDE_WGRAD and not torch.is_grad_enabled():
+            from . import conv as _conv
+            if _conv.side_ok(*ctx.params):
+                side = _conv._side(dev)
+        if side is None:
+            call("scnattn_seq_bwd", stream_of(enc), C.byref(d), C.byref(w), ptr(enc), ptr(tags), ptr(caps), ptr(dl_dev),
+                 C.cast(bt, C.c_void_p), ptr(drop_mask), ptr(saved), ptr(scratch), ptr(dpreds), ptr(dalphas),
+                 C.byref(g), ptr(denc), ptr(dtags), cpool)
+        else:
+            main = torch.cuda.current_stream(dev)
+            side.fork(main, enc, tags, caps, dl_dev, drop_mask, saved, scratch, dpreds, *weights, *grads)
+            call("scnattn_seq_bwd_streams", stream_of(enc), C.c_void_p(side.stream.cuda_stream), C.byref(d), C.byref(w),
+                 ptr(enc), ptr(tags), ptr(caps), ptr(dl_dev), C.cast(bt, C.c_void_p), ptr(drop_mask), ptr(saved),
+                 ptr(scratch), ptr(dpreds), ptr(dalphas), C.byref(g), ptr(denc), ptr(dtags), cpool)
+            side.mark()
         return (None, denc, dtags, None, None, None, *grads)
 
 

@@ -675,3 +675,57 @@ def test_dp_comm_through_the_c_abi_single_rank(dev):
     for p, q in zip(lin.parameters(), lin2.parameters()):
         assert torch.equal(p.grad, q.grad)
     comm.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# weight gradients of the decoder on the side stream (scnattn_seq_bwd_streams)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind,ragged", [("attention_scn", True), ("attention_scn", False), ("pure_scn", True)])
+def test_decoder_weight_gradients_on_the_side_stream_are_bit_identical(dev, kind, ragged):
+    """include/scnattn.h scnattn_seq_bwd_streams: same kernels, same operands, two streams ordered by events -- every
+    gradient must equal the single-stream call bit for bit.  The gradients are read on the main stream right after
+    `backward()` WITHOUT a device-wide synchronize: that the numbers are right also shows that the stream is joined at
+    the end of the autograd sweep (what the reference's clip_gradient / optimizer.step rely on).  A second backward into
+    existing .grad tensors must fall back to one stream (autograd adds on the main stream at once)."""
+    from models.decoders.attention_scn import AttentionSCN
+    from models.decoders.pure_scn import PureSCN
+    from oracle import scnattn_ref as R
+    from scnattn import functional as SF
+    torch.manual_seed(3)
+    B, V, L = 32, 1000, 12
+    m = (AttentionSCN(512, 512, 512, 512, 1000, V, dropout=0.5) if kind == "attention_scn"
+         else PureSCN(512, 512, 512, 1000, V, dropout=0.5)).to(dev).train()
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(B, 8, 8, 2048, generator=g).to(dev)
+    tags = torch.rand(B, 1000, generator=g).to(dev)
+    lens = torch.randint(5, L + 1, (B,), generator=g) if ragged else torch.full((B,), L)
+    caps = _synthetic_caps(B, V, L, lens, g).to(dev)
+    caplens = lens.unsqueeze(1).to(dev)
+    T = int(lens.max()) - 1
+    m.drop_mask_override = ((torch.rand(B, T, 512, generator=g) > 0.5).float() * 2.0).to(dev)
+
+    def run(side, keep_grads=False):
+        saved = SF.DECODER_SIDE_WGRAD
+        SF.DECODER_SIDE_WGRAD = side
+        try:
+            if not keep_grads:
+                for p in m.parameters():
+                    p.grad = None
+            x2 = x.clone().requires_grad_(True)
+            out = m(None, tags, caps, caplens, prepool=x2, pool_size=14)
+            alphas = out[3] if kind == "attention_scn" else None
+            loss, _, _ = R.caption_loss(out[0], out[1], out[2], alphas, 1.0)
+            loss.backward()
+            return {k: p.grad.clone() for k, p in m.named_parameters()}, x2.grad.clone()     # main stream, no sync
+        finally:
+            SF.DECODER_SIDE_WGRAD = saved
+
+    for _ in range(2):           # second round: allocator blocks of the first are being reused
+        one, dx1 = run(False)
+        two, dx2 = run(True)
+        assert torch.equal(dx1, dx2)
+        for k in one:
+            assert torch.equal(one[k], two[k]), k
+    acc, _ = run(True, keep_grads=True)      # accumulates into the gradients of the last run
+    for k in one:
+        _ok(acc[k], 2.0 * two[k], 1e-6, k)
