@@ -196,6 +196,12 @@ def main():
                     help="also run the frozen EncoderTagger ResNet-152 each step (the reference's real step)")
     ap.add_argument("--encoder-dtype", default="f32", choices=["f32", "bf16"],
                     help="bf16: ResNet trunk under bf16 autocast (BASELINE config 5 flavour; not the fp32 headline)")
+    ap.add_argument("--decoder-dtype", default="f32", choices=["f32", "bf16"],
+                    help="bf16: the decode step streams bf16 copies of the recurrent weights, att1 and the trunk map "
+                         "(fp32 accumulate / state / master weights / gradients)")
+    ap.add_argument("--dtype", default=None, choices=["f32", "bf16"],
+                    help="shorthand: bf16 = --encoder-dtype bf16 --decoder-dtype bf16 (BASELINE configs[4] flavour, a "
+                         "second line next to the fp32 headline)")
     ap.add_argument("--force-dist", action="store_true",
                     help="diagnostics: run the multi-rank code path (RCCL group, barriers, reducers) with one rank")
     ap.add_argument("--forward-only", action="store_true", help="diagnostics: decoder forward only (PMC passes)")
@@ -228,6 +234,8 @@ def main():
                          "trains/attention_scn.py:213-216) as the headline; by default it is timed as a second figure "
                          "(`drop_in_call` in the JSON line) after the harness sequence")
     args = ap.parse_args()
+    if args.dtype:
+        args.encoder_dtype = args.decoder_dtype = args.dtype
     os.environ["SCNATTN_DP_BACKEND"] = args.dp_backend
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -285,7 +293,8 @@ def main():
         dist.barrier()                                    # first collective on every rank
     ts = TrainStep(kind=args.workload, fine_tune_encoder=fine_tune, device=dev, encoder=not args.decoder_only,
                    batch_size=args.batch, max_len=args.max_len, graph_encoder=args.graph, tagger=args.with_tagger, force_reduce=args.force_dist,
-                   encoder_dtype=args.encoder_dtype, pooled_attention=not args.dense_attention, bucket_mb=args.bucket_mb)
+                   encoder_dtype=args.encoder_dtype, decoder_dtype=args.decoder_dtype,
+                   pooled_attention=not args.dense_attention, bucket_mb=args.bucket_mb)
     cfg = ts.cfg
     imgs, tags, caps, caplens = synthetic_batch(args.batch, cfg["vocab_size"], cfg["max_len"], cfg["image_size"],
                                                 cfg["semantic_dim"], dev, 1234 + rank)
@@ -388,7 +397,11 @@ def main():
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "loss_after_timed_steps": None if final_loss is None else round(final_loss, 4),
-            "dtype": "f32" if args.encoder_dtype == "f32" else "bf16 encoder convs (fp32 accumulate/master) + f32 decoder",
+            "dtype": {("f32", "f32"): "f32",
+                      ("bf16", "f32"): "bf16 encoder convs (fp32 accumulate/master) + f32 decoder",
+                      ("f32", "bf16"): "f32 encoder + bf16-storage decoder step (fp32 accumulate/state/master/gradients)",
+                      ("bf16", "bf16"): "bf16 encoder convs + bf16-storage decoder step (fp32 accumulate/state/master/gradients)"
+                      }[(args.encoder_dtype, args.decoder_dtype)],
             "data": "synthetic" if args.data == "synthetic" else
             "synthetic %d-image HDF5 split read through scnattn.data.DeviceBatchLoader (%s) inside the timed region"
             % (args.data_images, args.data),
@@ -424,7 +437,9 @@ def main():
             ach = ab / (step_us * 1e-6) / 1e9
             traffic, tsrc = None, None
             pooled = not args.dense_attention
-            pmc_name = "r01_pmc_decode_step_fwd_%s.json" % ("pooled" if pooled else "dense")
+            dbf = args.decoder_dtype == "bf16"
+            pmc_name = ("r02_pmc_decode_step_fwd_%s_bf16.json" if dbf else "r01_pmc_decode_step_fwd_%s.json") \
+                % ("pooled" if pooled else "dense")
             pmc = os.path.join(ROOT, "profiles", pmc_name)
             if args.batch == 32 and os.path.exists(pmc):   # PMC passes cannot run inside this process;
                 with open(pmc) as fh:                        # the committed rocprofv3 result is quoted
@@ -433,8 +448,10 @@ def main():
             # `achieved` prices the step at SURVEY 8d's algorithmic bytes (the reference's formulation: the pooled
             # 14x14 map is read every step).  The pooled path moves fewer: the context reads the 8x8 source map.
             eb = step_bytes(cfg, args.batch, P=64) + 4 * args.batch * (196 - 64) * cfg["attention_dim"] if pooled else ab
+            if dbf:            # every operand the step streams is stored as bf16 in this mode
+                eb //= 2
             ach_e = eb / (step_us * 1e-6) / 1e9
-            ctx_bytes = 4 * args.batch * (64 if pooled else 196) * 2048
+            ctx_bytes = (2 if dbf else 4) * args.batch * (64 if pooled else 196) * 2048
             if args.attn_handoff and pooled:      # the one-launch form also reads att1 (the scores live in it)
                 ctx_bytes += 4 * args.batch * 196 * cfg["attention_dim"]
             # "if an algebraic shortcut is used that executes fewer [bytes] than this formula, report

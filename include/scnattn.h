@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SCNATTN_VERSION 104 /* 0.1.4: + scnattn_seq_bwd_streams, scnattn_dp_comm_set_stream */
+#define SCNATTN_VERSION 105 /* 0.1.5: + bf16 storage mode of the sequence drivers, scnattn_seq_bwd_streams */
 
 int scnattn_version(void);
 const char* scnattn_last_error(void);
@@ -35,7 +35,9 @@ const char* scnattn_last_error(void);
  * "fuse_attn" (1: scores+softmax+context in one launch; slower, default 0),
  * "attn_handoff" (1: on the pooled path the attention scores and the context run as ONE launch whose E-chunk
  * workgroups share the scores of a batch row through an in-launch hand-off; default 0 = two launches: measured equal),
- * "handoff_check" (1: scnattn_seq_fwd synchronises at its end and returns an error if a hand-off wait timed out).
+ * "handoff_check" (1: scnattn_seq_fwd synchronises at its end and returns an error if a hand-off wait timed out),
+ * "decoder_bf16" (1: the sequence drivers stream bf16 copies of the recurrent weights, att1 and the encoder map --
+ * see scnattn_skinny_gemm_bf16w; needs D, F, E, A multiples of 4, otherwise the fp32 path runs).
  * Returns -1 for an unknown name or value. */
 int scnattn_set_option(const char* name, int value);
 /* Sums since the last call: out6 = {forward loop ms, forward steps, backward loop ms, backward steps,
@@ -167,6 +169,15 @@ int scnattn_sgemm_ws(void* stream, int transA, int transB, int M, int N, int K, 
 int scnattn_skinny_gemm(void* stream, int rows, int N, int K, int groups, const float* X, long ldx, long xg,
                         const float* W, long ldw, long wg, float* Y, long ldy, long yg, long yslab,
                         int ksplit, int* ksplit_out);
+/* Mixed precision (BASELINE configs[4]): the same product with the weight matrix stored as bf16 (raw 16-bit elements,
+ * ldw / wg in elements), widened to fp32 in registers, fp32 accumulation.  scnattn_f32_to_bf16 makes such a copy
+ * (round to nearest even; n % 4 == 0).  The sequence drivers use both when option "decoder_bf16" is 1: the operands
+ * the recurrence streams every step (recurrent weights, att1, the encoder map) are then read as bf16 copies made once
+ * per call; softmax, LSTM state, master weights and every gradient stay fp32. */
+int scnattn_skinny_gemm_bf16w(void* stream, int rows, int N, int K, int groups, const float* X, long ldx, long xg,
+                              const void* W_bf16, long ldw, long wg, float* Y, long ldy, long yg, long yslab,
+                              int ksplit, int* ksplit_out);
+int scnattn_f32_to_bf16(void* stream, long n, const float* in, void* out);
 /* models/attention.py:37-39 */
 int scnattn_attn_scores(void* stream, int rows, int P, int A, const float* att1, const float* att2, int nslab,
                         long slab_stride, long att2_ld, const float* dec_bias, const float* w, const float* b0,

@@ -24,7 +24,7 @@ extern int g_profile;
 extern int g_fuse_attn;
 extern int g_chains;
 extern int g_attn_depth;
-extern int g_attn_handoff, g_handoff_check;
+extern int g_attn_handoff, g_handoff_check, g_dec_bf16;
 extern int g_gemm_target, g_gemm_kmin, g_gemm_kmin_small, g_gemm_gate, g_use_cgemm, g_cgemm_target, g_cgemm_kmin, g_cgemm_vec, g_cgemm_mi;
 int profile_collect(double* out);
 int seq_workspace(const scnattn_dims* d, const scnattn_pool* pool, size_t* saved_bytes, size_t* scratch_bytes);
@@ -62,6 +62,7 @@ int scnattn_set_option(const char* name, int value) {
     }
     if (name && std::strcmp(name, "attn_depth") == 0) { g_attn_depth = value != 0; return 0; }
     if (name && std::strcmp(name, "attn_handoff") == 0) { g_attn_handoff = value != 0; return 0; }
+    if (name && std::strcmp(name, "decoder_bf16") == 0) { g_dec_bf16 = value != 0; return 0; }
     if (name && std::strcmp(name, "handoff_check") == 0) { g_handoff_check = value != 0; return 0; }
     if (name && std::strcmp(name, "gemm_target") == 0 && value >= 1) { g_gemm_target = value; return 0; }
     if (name && std::strcmp(name, "gemm_gate") == 0 && value >= 1) { g_gemm_gate = value; return 0; }
@@ -237,6 +238,16 @@ int scnattn_skinny_gemm(void* stream, int rows, int N, int K, int groups, const 
     if (ksplit_out) *ksplit_out = ksplit;
     return skinny_gemm(ST(stream), rows, N, K, groups, X, ldx, xg, W, ldw, wg, Y, ldy, yg, yslab, ksplit);
 }
+
+int scnattn_skinny_gemm_bf16w(void* stream, int rows, int N, int K, int groups, const float* X, long ldx, long xg,
+                              const void* W_bf16, long ldw, long wg, float* Y, long ldy, long yg, long yslab,
+                              int ksplit, int* ksplit_out) {
+    if (ksplit <= 0) ksplit = skinny_pick_ksplit(rows, N, K, groups);
+    if (ksplit_out) *ksplit_out = ksplit;
+    return skinny_gemm(ST(stream), rows, N, K, groups, X, ldx, xg, W_bf16, ldw, wg, Y, ldy, yg, yslab, ksplit, true);
+}
+
+int scnattn_f32_to_bf16(void* stream, long n, const float* in, void* out) { return f32_to_bf16(ST(stream), n, in, out); }
 
 int scnattn_attn_scores(void* stream, int rows, int P, int A, const float* att1, const float* att2, int nslab,
                         long slab_stride, long att2_ld, const float* dec_bias, const float* w, const float* b0,

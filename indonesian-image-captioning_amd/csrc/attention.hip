@@ -38,8 +38,8 @@ __device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) 
 }
 
 // ------------------------------------------------------------------------------------------------
-template <bool VEC>
-__global__ __launch_bounds__(256) void attn_scores_kernel(int rows, int P, int A, const float* __restrict__ att1,
+template <bool VEC, typename ET>
+__global__ __launch_bounds__(256) void attn_scores_kernel(int rows, int P, int A, const ET* __restrict__ att1,
                                                           Slabs att2, const float* __restrict__ bd,
                                                           const float* __restrict__ w, const float* __restrict__ b0,
                                                           float* __restrict__ e, float* __restrict__ att2_out) {
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(int rows, int P, int A
     }
     __syncthreads();
     // each wave: 4 pixel rows, independent accumulators (4 x 16 B loads in flight per lane)
-    const float* rowp[4];
+    const ET* rowp[4];
     bool ok[4];
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(int rows, int P, int A
             const f32x4 ww = *reinterpret_cast<const f32x4*>(ws + a);
             f32x4 v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4*>(rowp[j] + a);
+            for (int j = 0; j < 4; ++j) v[j] = ld4(rowp[j] + a);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(int rows, int P, int A
         for (int a = lane; a < A; a += 64) {
             const float s2 = att2s[a], ww = ws[a];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = fmaf(fmaxf(rowp[j][a] + s2, 0.f), ww, acc[j]);
+            for (int j = 0; j < 4; ++j) acc[j] = fmaf(fmaxf(ld1(rowp[j] + a) + s2, 0.f), ww, acc[j]);
         }
     }
     const float bias0 = b0 ? b0[0] : 0.f;
@@ -111,8 +111,8 @@ struct PoolQ {
     float* alphaq_save;     // [rows][Q]
 };
 
-template <bool VEC, int MODE, int CU, bool POOLED>
-__global__ __launch_bounds__(512) void attn_context_kernel(int rows, int P, int E, const float* __restrict__ enc,
+template <bool VEC, int MODE, int CU, bool POOLED, typename ET = float>
+__global__ __launch_bounds__(512) void attn_context_kernel(int rows, int P, int E, const ET* __restrict__ enc,
                                                            const float* __restrict__ e, Slabs gpre,
                                                            const float* __restrict__ bbeta,
                                                            float* __restrict__ alpha_out, long alpha_ld,
@@ -131,13 +131,13 @@ __global__ __launch_bounds__(512) void attn_context_kernel(int rows, int P, int 
     // a wave owns ceil(P/8) rows, and every extra batch is one more exposed memory latency, so the launcher
     // picks CU = 13 for P = 196 (25 rows per wave -> 2 batches instead of 4 with CU = 8).
     const int col = e0 + lane * 4;
-    const float* base = enc + (long)b * NR * E;
+    const ET* base = enc + (long)b * NR * E;
     const int cc = min(col, max(E - 4, 0));
     const bool cok = col < E;
     f32x4 v[CU];
     if (VEC) {
 #pragma unroll
-        for (int j = 0; j < CU; ++j) v[j] = *reinterpret_cast<const f32x4*>(base + (long)min(wave + 8 * j, NR - 1) * E + cc);
+        for (int j = 0; j < CU; ++j) v[j] = ld4(base + (long)min(wave + 8 * j, NR - 1) * E + cc);
     }
 
     if (MODE == 0) {
@@ -196,14 +196,14 @@ __global__ __launch_bounds__(512) void attn_context_kernel(int rows, int P, int 
             if (p >= NR) break;
 #pragma unroll
             for (int j = 0; j < CU; ++j)
-                v[j] = *reinterpret_cast<const f32x4*>(base + (long)min(p + 8 * j, NR - 1) * E + cc);
+                v[j] = ld4(base + (long)min(p + 8 * j, NR - 1) * E + cc);
         }
     } else {
         for (int p = wave; p < NR; p += 8) {
             const float al = MODE != 1 ? wts[p] : 1.f;
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                if (col + c < E) acc[c] = fmaf(al, base[(long)p * E + col + c], acc[c]);
+                if (col + c < E) acc[c] = fmaf(al, ld1(base + (long)p * E + col + c), acc[c]);
         }
     }
 #pragma unroll
@@ -524,8 +524,8 @@ __global__ __launch_bounds__(512) void attn_handoff_kernel(int rows, int P, int 
 }
 
 // ------------------------------------------------------------------------------------------------
-template <bool VEC, int U, int RW>
-__global__ __launch_bounds__(256) void attn_dalpha_kernel(int rows, int P, int E, const float* __restrict__ enc,
+template <bool VEC, int U, int RW, typename ET>
+__global__ __launch_bounds__(256) void attn_dalpha_kernel(int rows, int P, int E, const ET* __restrict__ enc,
                                                           const float* __restrict__ dawe,
                                                           const float* __restrict__ dalpha_in, long din_ld,
                                                           float* __restrict__ dalpha) {
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(256) void attn_dalpha_kernel(int rows, int P, int E
     const int E4 = (E + 3) & ~3;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, p0 = blockIdx.x * (4 * RW);
-    const float* rowp[RW];
+    const ET* rowp[RW];
     bool ok[RW];
     float acc[RW];
 #pragma unroll
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(256) void attn_dalpha_kernel(int rows, int P, int E
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int j = 0; j < RW; ++j) v[u][j] = *reinterpret_cast<const f32x4*>(rowp[j] + min(lane * 4 + 256 * u, cmax));
+            for (int j = 0; j < RW; ++j) v[u][j] = ld4(rowp[j] + min(lane * 4 + 256 * u, cmax));
         for (int c = tid; c < E4; c += 256) sm[c] = c < E ? dawe[(long)b * E + c] : 0.f;
         __syncthreads();
         for (int c0 = lane * 4;;) {
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(256) void attn_dalpha_kernel(int rows, int P, int E
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int j = 0; j < RW; ++j) v[u][j] = *reinterpret_cast<const f32x4*>(rowp[j] + min(c0 + 256 * u, cmax));
+                for (int j = 0; j < RW; ++j) v[u][j] = ld4(rowp[j] + min(c0 + 256 * u, cmax));
         }
     } else {
         for (int c = tid; c < E4; c += 256) sm[c] = c < E ? dawe[(long)b * E + c] : 0.f;
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256) void attn_dalpha_kernel(int rows, int P, int E
         for (int c = lane; c < E; c += 64) {
             const float d = sm[c];
 #pragma unroll
-            for (int j = 0; j < RW; ++j) acc[j] = fmaf(rowp[j][c], d, acc[j]);
+            for (int j = 0; j < RW; ++j) acc[j] = fmaf(ld1(rowp[j] + c), d, acc[j]);
         }
     }
 #pragma unroll
@@ -602,8 +602,8 @@ struct DalphaTaps {      // pooled path: d alpha is gathered from the Q source-p
     long din_ld;
 };
 
-template <bool VEC>
-__global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(int rows, int P, int A, const float* __restrict__ att1,
+template <bool VEC, typename ET>
+__global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(int rows, int P, int A, const ET* __restrict__ att1,
                                                                const float* __restrict__ att2,
                                                                const float* __restrict__ w,
                                                                const float* __restrict__ alpha,
@@ -652,7 +652,7 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(int rows, int P, 
     float s2[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) s2[c] = (a + c < A) ? att2[(long)b * A + a + c] : 0.f;
-    const float* base = att1 + (long)b * P * A;
+    const ET* base = att1 + (long)b * P * A;
     if (VEC) {
         const int ac = min(a, A - 4);
         const bool aok = a < A;
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(int rows, int P, 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int pp = p + 16 * j;
-                v[j] = *reinterpret_cast<const f32x4*>(base + (long)min(pp, P - 1) * A + ac);
+                v[j] = ld4(base + (long)min(pp, P - 1) * A + ac);
                 d[j] = (pp < P && aok) ? des[min(pp, P - 1)] : 0.f;
             }
 #pragma unroll
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(int rows, int P, 
             const float d = des[p];
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                if (a + c < A) acc[c] += (base[(long)p * A + a + c] + s2[c] > 0.f) ? d : 0.f;
+                if (a + c < A) acc[c] += (ld1(base + (long)p * A + a + c) + s2[c] > 0.f) ? d : 0.f;
         }
     }
 #pragma unroll
@@ -692,8 +692,9 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(int rows, int P, 
 // ------------------------------------------------------------------------------------------------
 constexpr int PC2 = 8;
 
+template <typename ET>
 __global__ __launch_bounds__(256) void attn_datt1_post_kernel(int B, int P, int A, int T, const int* __restrict__ dl,
-                                                              const float* __restrict__ att1,
+                                                              const ET* __restrict__ att1,
                                                               const float* __restrict__ att2_all,
                                                               const float* __restrict__ de_all,
                                                               const float* __restrict__ w, float* __restrict__ datt1,
@@ -713,7 +714,7 @@ __global__ __launch_bounds__(256) void attn_datt1_post_kernel(int B, int P, int 
         float a1[PC2], acc[PC2];
 #pragma unroll
         for (int j = 0; j < PC2; ++j) {
-            a1[j] = att1[((long)b * P + min(p0 + j, P - 1)) * A + a];
+            a1[j] = ld1(att1 + ((long)b * P + min(p0 + j, P - 1)) * A + a);
             acc[j] = 0.f;
         }
         float dwacc = 0.f;
@@ -745,24 +746,52 @@ __global__ __launch_bounds__(256) void attn_datt1_post_kernel(int B, int P, int 
 }  // namespace
 
 // ================================================================================================
-int attn_scores(hipStream_t st, int rows, int P, int A, const float* att1, Slabs att2, const float* bd,
-                const float* w, const float* b0, float* e, float* att2_out) {
+// bf16 storage: vector path = 8-byte loads of 4 elements
+static inline bool vec_ok(const void* p, int n, bool bf) {
+    return n % 4 == 0 && (reinterpret_cast<uintptr_t>(p) & (bf ? 7u : 15u)) == 0;
+}
+#define F32P(p) reinterpret_cast<const float*>(p)
+#define BF16P(p) reinterpret_cast<const bf16_t*>(p)
+
+int attn_scores(hipStream_t st, int rows, int P, int A, const void* att1, Slabs att2, const float* bd,
+                const float* w, const float* b0, float* e, float* att2_out, bool bf) {
     if (rows <= 0) return 0;
     SCN_ARG(att1 && att2.p && w && e && P > 0 && A > 0, "attn_scores: bad argument");
     dim3 grid(cdiv(P, PC), rows), block(256);
     const size_t lds = 2 * ((A + 3) & ~3) * sizeof(float);
     SCN_ARG(lds <= 64 * 1024, "attn_scores: attention_dim too large for the LDS staging");
-    if (A % 4 == 0 && aligned16(att1))
-        hipLaunchKernelGGL(attn_scores_kernel<true>, grid, block, lds, st, rows, P, A, att1, att2, bd, w, b0, e, att2_out);
-    else
-        hipLaunchKernelGGL(attn_scores_kernel<false>, grid, block, lds, st, rows, P, A, att1, att2, bd, w, b0, e, att2_out);
+    const bool vec = vec_ok(att1, A, bf);
+    if (bf) {
+        if (vec) hipLaunchKernelGGL((attn_scores_kernel<true, bf16_t>), grid, block, lds, st, rows, P, A, BF16P(att1), att2, bd, w, b0, e, att2_out);
+        else     hipLaunchKernelGGL((attn_scores_kernel<false, bf16_t>), grid, block, lds, st, rows, P, A, BF16P(att1), att2, bd, w, b0, e, att2_out);
+    } else {
+        if (vec) hipLaunchKernelGGL((attn_scores_kernel<true, float>), grid, block, lds, st, rows, P, A, F32P(att1), att2, bd, w, b0, e, att2_out);
+        else     hipLaunchKernelGGL((attn_scores_kernel<false, float>), grid, block, lds, st, rows, P, A, F32P(att1), att2, bd, w, b0, e, att2_out);
+    }
     SCN_LAUNCH_CHECK();
     return 0;
 }
 
-int attn_context(hipStream_t st, int rows, int P, int E, const float* enc, const float* e, Slabs gpre,
+int attn_context(hipStream_t st, int rows, int P, int E, const void* enc_, const float* e, Slabs gpre,
                  const float* bbeta, float* alpha_out, long alpha_ld, float* alpha_save, float* awe,
-                 float* gate, float* z) {
+                 float* gate, float* z, bool bf) {
+    if (bf) {     // bf16 storage: the dense map takes the pooled kernel's code path with an identity-free PoolQ
+        if (rows <= 0) return 0;
+        SCN_ARG(enc_ && e && awe && P > 0 && E > 0, "attn_context: bad argument");
+        dim3 grid(cdiv(E, 256), rows), block(512);
+        const size_t lds = (8 * 256 + 16 + P) * sizeof(float);
+        SCN_ARG(lds <= 64 * 1024, "attn_context: num_pixels too large for the LDS staging");
+        const PoolQ none{0, 0, nullptr, nullptr, nullptr};
+        if (vec_ok(enc_, E, true))
+            hipLaunchKernelGGL((attn_context_kernel<true, 0, 13, false, bf16_t>), grid, block, lds, st, rows, P, E, BF16P(enc_), e,
+                               gpre, bbeta, alpha_out, alpha_ld, alpha_save, awe, gate, z, none);
+        else
+            hipLaunchKernelGGL((attn_context_kernel<false, 0, 8, false, bf16_t>), grid, block, lds, st, rows, P, E, BF16P(enc_), e,
+                               gpre, bbeta, alpha_out, alpha_ld, alpha_save, awe, gate, z, none);
+        SCN_LAUNCH_CHECK();
+        return 0;
+    }
+    const float* enc = F32P(enc_);
     if (rows <= 0) return 0;
     SCN_ARG(enc && e && awe && P > 0 && E > 0, "attn_context: bad argument");
     dim3 grid(cdiv(E, 256), rows), block(512);
@@ -787,9 +816,10 @@ int attn_context(hipStream_t st, int rows, int P, int E, const float* enc, const
 }
 
 // attn_context over the un-pooled map x [rows][Q][E] (see PoolQ)
-int attn_context_pooled(hipStream_t st, int rows, int P, int E, const float* x, const PoolDesc& pool, const float* e,
+int attn_context_pooled(hipStream_t st, int rows, int P, int E, const void* x_, const PoolDesc& pool, const float* e,
                         Slabs gpre, const float* bbeta, float* alpha_out, long alpha_ld, float* alpha_save,
-                        float* alphaq_save, float* awe, float* gate, float* z) {
+                        float* alphaq_save, float* awe, float* gate, float* z, bool bf) {
+    const float* x = F32P(x_);
     if (rows <= 0) return 0;
     SCN_ARG(x && e && awe && P > 0 && E > 0 && pool.Q > 0 && pool.qtap_idx && pool.qtap_w, "attn_context_pooled: bad argument");
     dim3 grid(cdiv(E, 256), rows), block(512);
@@ -798,7 +828,14 @@ int attn_context_pooled(hipStream_t st, int rows, int P, int E, const float* x, 
     const PoolQ pq{pool.Q, pool.qtap_max, pool.qtap_idx, pool.qtap_w, alphaq_save};
     const int rpw = cdiv(pool.Q, 8);
     const bool deep = g_attn_depth && (rpw > 16 || (rpw > 8 && rpw <= 13));
-    if (E % 4 == 0 && aligned16(x)) {
+    if (bf) {
+        if (vec_ok(x_, E, true))
+            hipLaunchKernelGGL((attn_context_kernel<true, 0, 8, true, bf16_t>), grid, block, lds, st, rows, P, E, BF16P(x_), e,
+                               gpre, bbeta, alpha_out, alpha_ld, alpha_save, awe, gate, z, pq);
+        else
+            hipLaunchKernelGGL((attn_context_kernel<false, 0, 8, true, bf16_t>), grid, block, lds, st, rows, P, E, BF16P(x_), e,
+                               gpre, bbeta, alpha_out, alpha_ld, alpha_save, awe, gate, z, pq);
+    } else if (E % 4 == 0 && aligned16(x)) {
         if (deep)
             hipLaunchKernelGGL((attn_context_kernel<true, 0, 13, true>), grid, block, lds, st, rows, P, E, x, e, gpre,
                                bbeta, alpha_out, alpha_ld, alpha_save, awe, gate, z, pq);
@@ -876,48 +913,63 @@ int mean_pixels(hipStream_t st, int rows, int P, int E, const float* enc, float*
     return 0;
 }
 
-int attn_dalpha(hipStream_t st, int rows, int P, int E, const float* enc, const float* dawe,
-                const float* dalpha_in, long dalpha_in_ld, float* dalpha) {
+int attn_dalpha(hipStream_t st, int rows, int P, int E, const void* enc_, const float* dawe,
+                const float* dalpha_in, long dalpha_in_ld, float* dalpha, bool bf) {
+    const float* enc = F32P(enc_);
     if (rows <= 0) return 0;
     SCN_ARG(enc && dawe && dalpha && P > 0 && E > 0, "attn_dalpha: bad argument");
     const size_t lds = ((E + 3) & ~3) * sizeof(float);
     SCN_ARG(lds <= 64 * 1024, "attn_dalpha: encoder_dim too large for the LDS staging");
     dim3 block(256);
-    if (E % 4 == 0 && aligned16(enc)) {
+    if (bf) {
+        const bf16_t* eb = BF16P(enc_);
+        if (vec_ok(enc_, E, true)) {
+            if (E >= 2048 && P <= 128)
+                hipLaunchKernelGGL((attn_dalpha_kernel<true, 8, 2, bf16_t>), dim3(cdiv(P, 8), rows), block, lds, st, rows, P, E, eb, dawe, dalpha_in, dalpha_in_ld, dalpha);
+            else
+                hipLaunchKernelGGL((attn_dalpha_kernel<true, 4, 4, bf16_t>), dim3(cdiv(P, PC), rows), block, lds, st, rows, P, E, eb, dawe, dalpha_in, dalpha_in_ld, dalpha);
+        } else {
+            hipLaunchKernelGGL((attn_dalpha_kernel<false, 2, 4, bf16_t>), dim3(cdiv(P, PC), rows), block, lds, st, rows, P, E, eb, dawe, dalpha_in, dalpha_in_ld, dalpha);
+        }
+    } else if (E % 4 == 0 && aligned16(enc)) {
         if (g_attn_depth && E >= 2048 && P <= 128)       // few rows (the un-pooled map): more, shallower workgroups
-            hipLaunchKernelGGL((attn_dalpha_kernel<true, 8, 2>), dim3(cdiv(P, 8), rows), block, lds, st, rows, P, E, enc, dawe, dalpha_in, dalpha_in_ld, dalpha);
+            hipLaunchKernelGGL((attn_dalpha_kernel<true, 8, 2, float>), dim3(cdiv(P, 8), rows), block, lds, st, rows, P, E, enc, dawe, dalpha_in, dalpha_in_ld, dalpha);
         else if (g_attn_depth && E >= 1024)
-            hipLaunchKernelGGL((attn_dalpha_kernel<true, 4, 4>), dim3(cdiv(P, PC), rows), block, lds, st, rows, P, E, enc, dawe, dalpha_in, dalpha_in_ld, dalpha);
+            hipLaunchKernelGGL((attn_dalpha_kernel<true, 4, 4, float>), dim3(cdiv(P, PC), rows), block, lds, st, rows, P, E, enc, dawe, dalpha_in, dalpha_in_ld, dalpha);
         else
-            hipLaunchKernelGGL((attn_dalpha_kernel<true, 2, 4>), dim3(cdiv(P, PC), rows), block, lds, st, rows, P, E, enc, dawe, dalpha_in, dalpha_in_ld, dalpha);
+            hipLaunchKernelGGL((attn_dalpha_kernel<true, 2, 4, float>), dim3(cdiv(P, PC), rows), block, lds, st, rows, P, E, enc, dawe, dalpha_in, dalpha_in_ld, dalpha);
     } else {
-        hipLaunchKernelGGL((attn_dalpha_kernel<false, 2, 4>), dim3(cdiv(P, PC), rows), block, lds, st, rows, P, E, enc, dawe, dalpha_in, dalpha_in_ld, dalpha);
+        hipLaunchKernelGGL((attn_dalpha_kernel<false, 2, 4, float>), dim3(cdiv(P, PC), rows), block, lds, st, rows, P, E, enc, dawe, dalpha_in, dalpha_in_ld, dalpha);
     }
     SCN_LAUNCH_CHECK();
     return 0;
 }
 
-int attn_softmax_bwd(hipStream_t st, int rows, int P, int A, const float* att1, const float* att2,
+int attn_softmax_bwd(hipStream_t st, int rows, int P, int A, const void* att1, const float* att2,
                      const float* w, const float* alpha, const float* dalpha, float* de, float* datt2,
-                     long datt2_ld) {
+                     long datt2_ld, bool bf) {
     if (rows <= 0) return 0;
     SCN_ARG(att1 && att2 && w && alpha && dalpha && datt2 && P > 0 && A > 0, "attn_softmax_bwd: bad argument");
     dim3 grid(cdiv(A, 64), rows), block(256);
     const size_t lds = (16 * 64 + 16 + P) * sizeof(float);
     SCN_ARG(lds <= 64 * 1024, "attn_softmax_bwd: num_pixels too large for the LDS staging");
     const DalphaTaps none{nullptr, nullptr, nullptr, 0, nullptr, 0};
-    if (A % 4 == 0 && aligned16(att1))
-        hipLaunchKernelGGL(attn_softmax_bwd_kernel<true>, grid, block, lds, st, rows, P, A, att1, att2, w, alpha, dalpha, de, datt2, datt2_ld, none);
-    else
-        hipLaunchKernelGGL(attn_softmax_bwd_kernel<false>, grid, block, lds, st, rows, P, A, att1, att2, w, alpha, dalpha, de, datt2, datt2_ld, none);
+    const bool vec = vec_ok(att1, A, bf);
+    if (bf) {
+        if (vec) hipLaunchKernelGGL((attn_softmax_bwd_kernel<true, bf16_t>), grid, block, lds, st, rows, P, A, BF16P(att1), att2, w, alpha, dalpha, de, datt2, datt2_ld, none);
+        else     hipLaunchKernelGGL((attn_softmax_bwd_kernel<false, bf16_t>), grid, block, lds, st, rows, P, A, BF16P(att1), att2, w, alpha, dalpha, de, datt2, datt2_ld, none);
+    } else {
+        if (vec) hipLaunchKernelGGL((attn_softmax_bwd_kernel<true, float>), grid, block, lds, st, rows, P, A, F32P(att1), att2, w, alpha, dalpha, de, datt2, datt2_ld, none);
+        else     hipLaunchKernelGGL((attn_softmax_bwd_kernel<false, float>), grid, block, lds, st, rows, P, A, F32P(att1), att2, w, alpha, dalpha, de, datt2, datt2_ld, none);
+    }
     SCN_LAUNCH_CHECK();
     return 0;
 }
 
 // softmax backward whose d alpha comes from the source-pixel dot products dalphaq [rows][Q] through the pool taps
-int attn_softmax_bwd_pooled(hipStream_t st, int rows, int P, int A, const float* att1, const float* att2, const float* w,
+int attn_softmax_bwd_pooled(hipStream_t st, int rows, int P, int A, const void* att1, const float* att2, const float* w,
                             const float* alpha, const PoolDesc& pool, const float* dalphaq, const float* dalpha_in,
-                            long dalpha_in_ld, float* de, float* datt2, long datt2_ld) {
+                            long dalpha_in_ld, float* de, float* datt2, long datt2_ld, bool bf) {
     if (rows <= 0) return 0;
     SCN_ARG(att1 && att2 && w && alpha && dalphaq && datt2 && P > 0 && A > 0 && pool.tap_idx && pool.tap_w,
             "attn_softmax_bwd_pooled: bad argument");
@@ -925,10 +977,15 @@ int attn_softmax_bwd_pooled(hipStream_t st, int rows, int P, int A, const float*
     const size_t lds = (16 * 64 + 16 + P) * sizeof(float);
     SCN_ARG(lds <= 64 * 1024 && pool.Q <= 16 * 64, "attn_softmax_bwd: num_pixels too large for the LDS staging");
     const DalphaTaps dt{pool.tap_idx, pool.tap_w, dalphaq, pool.Q, dalpha_in, dalpha_in_ld};
-    if (A % 4 == 0 && aligned16(att1))
-        hipLaunchKernelGGL(attn_softmax_bwd_kernel<true>, grid, block, lds, st, rows, P, A, att1, att2, w, alpha, (const float*)nullptr, de, datt2, datt2_ld, dt);
-    else
-        hipLaunchKernelGGL(attn_softmax_bwd_kernel<false>, grid, block, lds, st, rows, P, A, att1, att2, w, alpha, (const float*)nullptr, de, datt2, datt2_ld, dt);
+    const bool vec = vec_ok(att1, A, bf);
+    const float* nodal = nullptr;
+    if (bf) {
+        if (vec) hipLaunchKernelGGL((attn_softmax_bwd_kernel<true, bf16_t>), grid, block, lds, st, rows, P, A, BF16P(att1), att2, w, alpha, nodal, de, datt2, datt2_ld, dt);
+        else     hipLaunchKernelGGL((attn_softmax_bwd_kernel<false, bf16_t>), grid, block, lds, st, rows, P, A, BF16P(att1), att2, w, alpha, nodal, de, datt2, datt2_ld, dt);
+    } else {
+        if (vec) hipLaunchKernelGGL((attn_softmax_bwd_kernel<true, float>), grid, block, lds, st, rows, P, A, F32P(att1), att2, w, alpha, nodal, de, datt2, datt2_ld, dt);
+        else     hipLaunchKernelGGL((attn_softmax_bwd_kernel<false, float>), grid, block, lds, st, rows, P, A, F32P(att1), att2, w, alpha, nodal, de, datt2, datt2_ld, dt);
+    }
     SCN_LAUNCH_CHECK();
     return 0;
 }
@@ -1028,16 +1085,17 @@ int add_bcast_rows_w(hipStream_t st, int B, int Q, int E, const float* wts, cons
     return 0;
 }
 
-int attn_datt1_post(hipStream_t st, int B, int P, int A, int T, const int* dl, const float* att1,
+int attn_datt1_post(hipStream_t st, int B, int P, int A, int T, const int* dl, const void* att1,
                     const float* att2_all, const float* de_all, const float* w, float* datt1,
-                    float* dwpart, int* nblocks_out) {
+                    float* dwpart, int* nblocks_out, bool bf) {
     SCN_ARG(B > 0 && P > 0 && A > 0 && T > 0, "attn_datt1_post: bad dims");
     SCN_ARG(dl && att1 && att2_all && de_all && w && datt1 && dwpart, "attn_datt1_post: null operand");
     dim3 grid(cdiv(P, PC2), B), block(256);
     const size_t lds = (size_t)T * PC2 * sizeof(float);
     SCN_ARG(lds <= 64 * 1024, "attn_datt1_post: too many timesteps for the LDS staging");
     if (nblocks_out) *nblocks_out = grid.x * grid.y;
-    hipLaunchKernelGGL(attn_datt1_post_kernel, grid, block, lds, st, B, P, A, T, dl, att1, att2_all, de_all, w, datt1, dwpart);
+    if (bf) hipLaunchKernelGGL(attn_datt1_post_kernel<bf16_t>, grid, block, lds, st, B, P, A, T, dl, BF16P(att1), att2_all, de_all, w, datt1, dwpart);
+    else    hipLaunchKernelGGL(attn_datt1_post_kernel<float>, grid, block, lds, st, B, P, A, T, dl, F32P(att1), att2_all, de_all, w, datt1, dwpart);
     SCN_LAUNCH_CHECK();
     return 0;
 }

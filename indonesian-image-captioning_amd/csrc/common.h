@@ -55,6 +55,26 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// ---- bf16 STORAGE of streamed operands (BASELINE configs[4]: mixed precision) --------------------------
+// The decode step is bound by the bytes it streams (recurrent weights, att1, the trunk map), not by arithmetic:
+// in the bf16 mode those operands are stored as bf16 and widened to fp32 in registers; every product is
+// accumulated in fp32 and softmax / LSTM state / master weights / gradients stay fp32.
+typedef unsigned short bf16_t;      // raw bits (the upper half of an IEEE fp32)
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float bf16_to_f32(unsigned v) { return __builtin_bit_cast(float, v << 16); }
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 ld4(const bf16_t* p) {     // 4 consecutive elements: one 8-byte load
+    const u32x2 u = *reinterpret_cast<const u32x2*>(p);
+    f32x4 r;
+    r[0] = __builtin_bit_cast(float, u[0] << 16);
+    r[1] = __builtin_bit_cast(float, u[0] & 0xffff0000u);
+    r[2] = __builtin_bit_cast(float, u[1] << 16);
+    r[3] = __builtin_bit_cast(float, u[1] & 0xffff0000u);
+    return r;
+}
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const bf16_t* p) { return bf16_to_f32(*p); }
+
 // Sum `nslab` partial slabs (split-K outputs of skinny_gemm) at element `idx`, fixed order.
 // All loads are issued before the first add (a run-time-bounded loop would serialise one memory
 // latency per slab): loads beyond n re-read the last slab (a cache hit) and are discarded.

@@ -44,8 +44,9 @@ int cgemm_row_tiles(int M);
 
 // ---- skinny.hip ------------------------------------------------------------------------------
 int skinny_pick_ksplit(int rows, int N, int K, int groups);
+// wbf: W holds bf16 (raw 16-bit) elements, ldw / wg still count elements
 int skinny_gemm(hipStream_t st, int rows, int N, int K, int groups, const float* X, long ldx, long xg,
-                const float* W, long ldw, long wg, float* Y, long ldy, long yg, long yslab, int ksplit);
+                const void* W, long ldw, long wg, float* Y, long ldy, long yg, long yslab, int ksplit, bool wbf = false);
 
 // A split-K result: `n` slabs `stride` elements apart, row leading dimension `ld`.
 struct Slabs {
@@ -54,13 +55,14 @@ struct Slabs {
 
 // ---- attention.hip ---------------------------------------------------------------------------
 // e[b,p] = w . relu(att1[b,p,:] + att2[b,:]) + b0, att2 = sum(slabs) + bd   (attention.py:37-39)
-int attn_scores(hipStream_t st, int rows, int P, int A, const float* att1, Slabs att2, const float* bd,
-                const float* w, const float* b0, float* e, float* att2_out);
+// bf (here and below): the streamed operand (att1 / enc / x) holds bf16 elements
+int attn_scores(hipStream_t st, int rows, int P, int A, const void* att1, Slabs att2, const float* bd,
+                const float* w, const float* b0, float* e, float* att2_out, bool bf = false);
 // alpha = softmax_p(e); awe = sum_p alpha*enc; z = sigmoid(gpre + bbeta) * awe   (attention.py:40-42,
 // attention_scn.py:147-148).  gpre.p == nullptr -> no gate (z = awe, gate not written).
-int attn_context(hipStream_t st, int rows, int P, int E, const float* enc, const float* e, Slabs gpre,
+int attn_context(hipStream_t st, int rows, int P, int E, const void* enc, const float* e, Slabs gpre,
                  const float* bbeta, float* alpha_out, long alpha_ld, float* alpha_save, float* awe,
-                 float* gate, float* z);
+                 float* gate, float* z, bool bf = false);
 // scores + softmax + context + gate in ONE launch (sequence path); attn_fused_ok() says whether the shape
 // qualifies (16-byte alignment, LDS budget), otherwise use attn_scores + attn_context
 bool attn_fused_ok(int P, int E, int A, const float* enc, const float* att1);
@@ -78,9 +80,9 @@ struct PoolDesc {
     const float* qtap_w;    // [Q][qtap_max]
     const float* col_w;     // [Q]: column sums of the pooling matrix / P (pixel mean of the pooled map)
 };
-int attn_context_pooled(hipStream_t st, int rows, int P, int E, const float* x, const PoolDesc& pool, const float* e,
+int attn_context_pooled(hipStream_t st, int rows, int P, int E, const void* x, const PoolDesc& pool, const float* e,
                         Slabs gpre, const float* bbeta, float* alpha_out, long alpha_ld, float* alpha_save,
-                        float* alphaq_save, float* awe, float* gate, float* z);
+                        float* alphaq_save, float* awe, float* gate, float* z, bool bf = false);
 // scores + softmax + pooled context + gate in one launch (in-launch hand-off of the scores between the E-chunk
 // workgroups of a batch row); e_buf [rows][P], cnt [rows] (zeroed once per sequence), errflag [1]; step = decode step
 bool attn_handoff_ok(int rows, int P, int E, int A, const float* x, const float* att1, const PoolDesc& pool);
@@ -89,23 +91,23 @@ int attn_handoff(hipStream_t st, int rows, int P, int E, int A, int step, const 
                  const float* bbeta, float* e_buf, int* cnt, int* errflag, float* alpha_out, long alpha_ld,
                  float* alpha_save, float* alphaq_save, float* att2_out, float* awe, float* gate, float* z);
 int weighted_rows(hipStream_t st, int rows, int Q, int E, const float* x, const float* wts, float* out);
-int attn_softmax_bwd_pooled(hipStream_t st, int rows, int P, int A, const float* att1, const float* att2, const float* w,
+int attn_softmax_bwd_pooled(hipStream_t st, int rows, int P, int A, const void* att1, const float* att2, const float* w,
                             const float* alpha, const PoolDesc& pool, const float* dalphaq, const float* dalpha_in,
-                            long dalpha_in_ld, float* de, float* datt2, long datt2_ld);
+                            long dalpha_in_ld, float* de, float* datt2, long datt2_ld, bool bf = false);
 int pool_expand(hipStream_t st, int B, int P, int A, const PoolDesc& pool, const float* y, const float* bias, float* out);
 int pool_transpose(hipStream_t st, int B, int P, int A, const PoolDesc& pool, const float* in, float* out);
 int add_bcast_rows_w(hipStream_t st, int B, int Q, int E, const float* wts, const float* v, float* out);
-int attn_dalpha(hipStream_t st, int rows, int P, int E, const float* enc, const float* dawe,
-                const float* dalpha_in, long dalpha_in_ld, float* dalpha);
+int attn_dalpha(hipStream_t st, int rows, int P, int E, const void* enc, const float* dawe,
+                const float* dalpha_in, long dalpha_in_ld, float* dalpha, bool bf = false);
 // de = alpha*(dalpha - sum(alpha*dalpha));  datt2[b,a] = w[a] * sum_p de[b,p]*[att1+att2 > 0]
-int attn_softmax_bwd(hipStream_t st, int rows, int P, int A, const float* att1, const float* att2,
+int attn_softmax_bwd(hipStream_t st, int rows, int P, int A, const void* att1, const float* att2,
                      const float* w, const float* alpha, const float* dalpha, float* de, float* datt2,
-                     long datt2_ld);
+                     long datt2_ld, bool bf = false);
 // After the time loop: datt1[b,p,a] = w[a]*sum_t de_t[b,p]*[att1+att2_t>0]; per-block partials of
 // dw[a] = sum de_t*relu(att1+att2_t) and db0 = sum de_t in dwpart[block][A+1].
-int attn_datt1_post(hipStream_t st, int B, int P, int A, int T, const int* dl, const float* att1,
+int attn_datt1_post(hipStream_t st, int B, int P, int A, int T, const int* dl, const void* att1,
                     const float* att2_all, const float* de_all, const float* w, float* datt1,
-                    float* dwpart, int* nblocks_out);
+                    float* dwpart, int* nblocks_out, bool bf = false);
 int attn_datt1_post_blocks(int B, int P);
 
 // ---- scn_cell.hip ----------------------------------------------------------------------------
@@ -153,6 +155,8 @@ int clamp_adam(hipStream_t st, long n, float* p, const float* g, float* m, float
                double b2, double eps, int step, double clip, double gscale);
 int mul_bcast(hipStream_t st, int T, int B, int N, const float* x, const float* q, float* out);
 int reduce_slabs(hipStream_t st, int rows, int N, Slabs s, float* out);
+// fp32 -> bf16 (round to nearest even), n elements (n % 4 == 0, 16-byte aligned input)
+int f32_to_bf16(hipStream_t st, long n, const float* in, void* out);
 
 // ---- batchnorm.hip (channels-last feature maps as [R = N*H*W, C] matrices) --------------------------
 int bn_max_chunks();

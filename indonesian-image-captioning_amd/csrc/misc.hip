@@ -265,6 +265,22 @@ __global__ __launch_bounds__(256) void mul_bcast_kernel(int T, int B, int N, con
     out[i] = x[i] * q[i % ((long)B * N)];
 }
 
+// fp32 -> bf16, round to nearest even (NaN kept quiet): the storage conversion of the bf16 decoder mode
+__device__ __forceinline__ unsigned f2bf(float f) {
+    const unsigned u = __builtin_bit_cast(unsigned, f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(long n4, const float* __restrict__ in, bf16_t* __restrict__ out) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(in + 4 * i);
+        u32x2 o;
+        o[0] = f2bf(v[0]) | (f2bf(v[1]) << 16);
+        o[1] = f2bf(v[2]) | (f2bf(v[3]) << 16);
+        *reinterpret_cast<u32x2*>(out + 4 * i) = o;
+    }
+}
+
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(int rows, int N, Slabs s, float* __restrict__ out) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)rows * N) return;
@@ -278,6 +294,17 @@ int mul_bcast(hipStream_t st, int T, int B, int N, const float* x, const float* 
     if (T <= 0 || B <= 0 || N <= 0) return 0;
     SCN_ARG(x && q && out, "mul_bcast: null operand");
     hipLaunchKernelGGL(mul_bcast_kernel, dim3(cdiv((long)T * B * N, 256)), dim3(256), 0, st, T, B, N, x, q, out);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
+int f32_to_bf16(hipStream_t st, long n, const float* in, void* out) {
+    if (n <= 0) return 0;
+    SCN_ARG(in && out && n % 4 == 0 && aligned16(in) && (reinterpret_cast<uintptr_t>(out) & 7u) == 0,
+            "f32_to_bf16: n must be a multiple of 4 and the buffers vector aligned");
+    const long n4 = n / 4;
+    const int blocks = (int)(n4 / 256 > 4096 ? 4096 : (n4 + 255) / 256);
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(blocks), dim3(256), 0, st, n4, in, reinterpret_cast<bf16_t*>(out));
     SCN_LAUNCH_CHECK();
     return 0;
 }

@@ -31,6 +31,9 @@ int g_fuse_attn = 0;     // 1: scores+softmax+context+gate as one launch (measur
                          //    each E-chunk workgroup recomputes all 196 scores through its CU's L2 port)
 extern int g_attn_handoff;   // 1: pooled path runs scores + context as one launch with an in-launch hand-off (default 0: not faster)
 int g_handoff_check = 0;     // 1: seq_fwd synchronises at its end and reports a hand-off time-out (tests)
+int g_dec_bf16 = 0;          // 1: BASELINE configs[4] flavour -- the operands the recurrence STREAMS every step (recurrent
+                             //    weights, att1, the encoder map) are kept as bf16 copies, made once per call; products
+                             //    accumulate in fp32, softmax / LSTM state / master weights / every gradient stay fp32
 
 // ---- optional in-stream timing of the recurrence loops (bench.py's roofline figure) ------------------
 struct LoopEvent { hipEvent_t a, b; int kind, steps; };
@@ -90,18 +93,20 @@ struct Carver {
 struct Saved {
     float *att1, *qx, *qh, *ex, *emb_tm, *mean_enc, *Hs, *Cs, *att2_all, *alpha_tm, *awe_all, *gate_all, *z_all,
         *pa_all, *ph_all, *gates_all, *tanhc_all, *Hd_bm, *rowmask, *alphaq_tm;
+    float *att1h, *ench;      // bf16 copies (raw 16-bit elements) of att1 and of the encoder map, bf16 mode only
 };
 
 constexpr long GEMM_WS_FLOATS = 8L << 20;   // 32 MiB of split-K partials for the big GEMMs
 
 struct FwdScratch {
     float *WcatA, *WD, *slabA, *e, *slabC, *xcat, *slabD, *gws, *y, *cnt;
+    float *WcatAh, *WDh, *WaMh;      // bf16 copies of the per-step weight operands
 };
 
 struct BwdScratch {
     float *WDb, *WaTz, *WcatT, *dHd_bm, *dhfc_tm, *dr_all, *dpx_all, *dcat_all, *dawe_all, *de_all, *dalpha, *dc,
         *dqx_acc, *dqh_acc, *sDb, *sZ, *sH, *datt1, *dwpart, *dwtmp, *demb_tm, *dmean, *dh0, *mx_all, *gws, *present,
-        *dalphaq, *dy, *gws2;
+        *dalphaq, *dy, *gws2, *WDbh, *WaTzh, *WcatTh;
 };
 
 inline size_t sz(long a, long b = 1, long c = 1, long d = 1) { return (size_t)a * b * c * d; }
@@ -130,6 +135,8 @@ size_t carve_saved(const scnattn_dims& d, int Q, float* base, Saved& s) {
     s.Hd_bm = c.take(sz(B, T, D));
     s.rowmask = c.take(sz(B, T));
     s.alphaq_tm = (d.has_att && Q > 0) ? c.take(sz(T, B, Q)) : nullptr;
+    s.att1h = d.has_att ? c.take((sz(B, P, A) + 1) / 2) : nullptr;
+    s.ench = d.has_att ? c.take((sz(B, Q > 0 ? Q : P, E) + 1) / 2) : nullptr;
     return c.off * sizeof(float);
 }
 
@@ -148,6 +155,9 @@ size_t carve_fwd(const scnattn_dims& d, int Q, float* base, FwdScratch& s) {
     s.gws = c.take(GEMM_WS_FLOATS);
     s.y = (d.has_att && Q > 0) ? c.take(sz(B, Q, d.A)) : nullptr;
     s.cnt = (d.has_att && Q > 0) ? c.take(sz(B + 1)) : nullptr;    // hand-off counters [B] + time-out flag [1] (ints)
+    s.WcatAh = c.take((sz(D, NA) + 1) / 2);
+    s.WDh = c.take((sz(4, 2 * F, D) + 1) / 2);
+    s.WaMh = d.has_att ? c.take((sz(d.E, 4 * F) + 1) / 2) : nullptr;
     return c.off * sizeof(float);
 }
 
@@ -183,6 +193,9 @@ size_t carve_bwd(const scnattn_dims& d, int Q, float* base, BwdScratch& s) {
     s.dalphaq = (d.has_att && Q > 0) ? c.take(sz(B, Q)) : nullptr;
     s.dy = (d.has_att && Q > 0) ? c.take(sz(B, Q, A)) : nullptr;
     s.gws2 = c.take(GEMM_WS_FLOATS);      // split-K partials of the weight-gradient stream
+    s.WDbh = c.take((sz(4, D, 2 * F) + 1) / 2);
+    s.WaTzh = d.has_att ? c.take((sz(F4, E) + 1) / 2) : nullptr;
+    s.WcatTh = c.take((sz(NC, D) + 1) / 2);
     return c.off * sizeof(float);
 }
 
@@ -215,6 +228,15 @@ int check_pool(const scnattn_dims* d, const scnattn_pool* p, PoolDesc& out) {
             "scnattn_pool: attention_dim and encoder_dim must be multiples of 4");
     out = PoolDesc{p->Q, p->qtap_max, p->tap_idx, p->tap_w, p->qtap_idx, p->qtap_w, p->col_w};
     return 0;
+}
+
+// bf16 storage mode: every converted buffer must be a whole number of 4-element groups
+inline bool bf16_mode(const scnattn_dims& d) {
+    return g_dec_bf16 && d.D % 4 == 0 && d.F % 4 == 0 && d.E % 4 == 0 && (!d.has_att || d.A % 4 == 0);
+}
+// element offset into a buffer that holds fp32 or bf16 elements
+inline const void* eoff(const void* base, long elems, bool bf) {
+    return reinterpret_cast<const char*>(base) + elems * (bf ? 2 : 4);
 }
 
 inline int pick(int rows, int N, int K, int groups) {
@@ -341,6 +363,16 @@ int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
         SCN_TRY(transpose2d(st, D, F, w->decode_step_weight_hc + g * F, F4, wd + (long)F * D, D));  // Hc_g^T
     }
 
+    const bool bf = bf16_mode(d);
+    if (bf) {
+        SCN_TRY(f32_to_bf16(st, sz(D, NA), f.WcatA, f.WcatAh));
+        SCN_TRY(f32_to_bf16(st, sz(4, 2 * F, D), f.WD, f.WDh));
+        if (d.has_att) SCN_TRY(f32_to_bf16(st, sz(E, F4), w->decode_step_weight_ia + (long)M * F4, f.WaMh));
+    }
+    const void* WcatA = bf ? (const void*)f.WcatAh : f.WcatA;
+    const void* WD = bf ? (const void*)f.WDh : f.WD;
+    const void* WaM = bf ? (const void*)f.WaMh : (d.has_att ? w->decode_step_weight_ia + (long)M * F4 : nullptr);
+
     // ---- time-invariant pieces -----------------------------------------------------------------
     if (d.has_att && Q > 0) {
         // att1 = pool(x) . We^T + be = pool(x . We^T) + be: the projection runs on Q rows per image, not P
@@ -351,6 +383,12 @@ int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
         SCN_TRY(sgemm_ws(st, false, true, B * P, A, E, 1.f, enc, E, w->attention_encoder_att_weight, E, 0.f, s.att1, A,
                       w->attention_encoder_att_bias, nullptr, 1, 0, 0, 0, f.gws, GEMM_WS_FLOATS));
     }
+    if (bf && d.has_att) {     // what the step kernels stream: bf16 copies of att1 and of the map the context is summed over
+        SCN_TRY(f32_to_bf16(st, sz(B, P, A), s.att1, s.att1h));
+        SCN_TRY(f32_to_bf16(st, sz(B, Q > 0 ? Q : P, E), enc, s.ench));
+    }
+    const void* att1_s = (bf && d.has_att) ? (const void*)s.att1h : s.att1;
+    const void* enc_s = (bf && d.has_att) ? (const void*)s.ench : enc;
     SCN_TRY(sgemm_ws(st, false, false, B, F4, d.S, 1.f, tags, d.S, w->decode_step_weight_ib, F4, 0.f, s.qx, F4, nullptr,
                   nullptr, 1, 0, 0, 0, f.gws, GEMM_WS_FLOATS));
     SCN_TRY(sgemm_ws(st, false, false, B, F4, d.S, 1.f, tags, d.S, w->decode_step_weight_hb, F4, 0.f, s.qh, F4, nullptr,
@@ -367,12 +405,12 @@ int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
 
     // ---- the recurrence --------------------------------------------------------------------------
     const long BD = (long)B * D;
-    const bool handoff = d.has_att && Q > 0 && attn_handoff_ok(B, P, E, A, enc, s.att1, pd);
+    const bool handoff = !bf && d.has_att && Q > 0 && attn_handoff_ok(B, P, E, A, enc, s.att1, pd);
     if (handoff) SCN_HIP(hipMemsetAsync(f.cnt, 0, sizeof(int) * (B + 1), st));
     hipEvent_t ev0 = prof_begin(st);
     SCN_TRY(run_chains(st, 0, B, [&](hipStream_t cs, int r0, int rmax) -> int {
-        const float* enc_c = enc + (long)r0 * (Q > 0 ? Q : P) * E;
-        const float* att1_c = d.has_att ? s.att1 + (long)r0 * P * A : nullptr;
+        const void* enc_c = eoff(enc_s, (long)r0 * (Q > 0 ? Q : P) * E, bf && d.has_att);
+        const void* att1_c = d.has_att ? eoff(att1_s, (long)r0 * P * A, bf) : nullptr;
         float* slabA = f.slabA + (long)r0 * NA;
         float* slabC = d.has_att ? f.slabC + (long)r0 * F4 : nullptr;
         float* slabD = f.slabD + (long)r0 * D;
@@ -387,14 +425,14 @@ int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
             const float* h = s.Hs + rowT * D;
             const float* c = s.Cs + rowT * D;
             const int ksA = pick(bt_, NA, D, 1);
-            SCN_TRY(skinny_gemm(cs, bt_, NA, D, 1, h, D, 0, f.WcatA, NA, 0, slabA, NA, 0, (long)B * NA, ksA));
+            SCN_TRY(skinny_gemm(cs, bt_, NA, D, 1, h, D, 0, WcatA, NA, 0, slabA, NA, 0, (long)B * NA, ksA, bf));
             Slabs pz{nullptr, 0, 0, 0};
             if (d.has_att) {
                 float* alpha_out = alphas + (long)r0 * T * P + (long)t * P;
                 if (handoff) {
                     hipEvent_t evc = g_profile >= 2 ? prof_begin(cs) : nullptr;
                     int* cnt = reinterpret_cast<int*>(f.cnt);
-                    SCN_TRY(attn_handoff(cs, bt_, P, E, A, t, enc_c, att1_c, pd, Slabs{slabA, ksA, (long)B * NA, NA},
+                    SCN_TRY(attn_handoff(cs, bt_, P, E, A, t, (const float*)enc_c, (const float*)att1_c, pd, Slabs{slabA, ksA, (long)B * NA, NA},
                                          w->attention_decoder_att_bias, w->attention_full_att_weight,
                                          w->attention_full_att_bias, Slabs{slabA + A, ksA, (long)B * NA, NA},
                                          w->f_beta_bias, e_c, cnt + r0, cnt + B, alpha_out, (long)T * P,
@@ -404,16 +442,16 @@ int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
                 } else if (Q > 0) {
                     SCN_TRY(attn_scores(cs, bt_, P, A, att1_c, Slabs{slabA, ksA, (long)B * NA, NA},
                                         w->attention_decoder_att_bias, w->attention_full_att_weight,
-                                        w->attention_full_att_bias, e_c, s.att2_all + rowT * A));
+                                        w->attention_full_att_bias, e_c, s.att2_all + rowT * A, bf));
                     hipEvent_t evc = g_profile >= 2 ? prof_begin(cs) : nullptr;
                     SCN_TRY(attn_context_pooled(cs, bt_, P, E, enc_c, pd, e_c, Slabs{slabA + A, ksA, (long)B * NA, NA},
                                                 w->f_beta_bias, alpha_out, (long)T * P, s.alpha_tm + rowT * P,
                                                 s.alphaq_tm + rowT * Q, s.awe_all + rowT * E, s.gate_all + rowT * E,
-                                                s.z_all + rowT * E));
+                                                s.z_all + rowT * E, bf));
                     prof_end(cs, evc, 2, 1);
-                } else if (g_fuse_attn && attn_fused_ok(P, E, A, enc_c, att1_c)) {
+                } else if (!bf && g_fuse_attn && attn_fused_ok(P, E, A, (const float*)enc_c, (const float*)att1_c)) {
                     hipEvent_t evc = g_profile >= 2 ? prof_begin(cs) : nullptr;
-                    SCN_TRY(attn_fused(cs, bt_, P, E, A, enc_c, att1_c, Slabs{slabA, ksA, (long)B * NA, NA},
+                    SCN_TRY(attn_fused(cs, bt_, P, E, A, (const float*)enc_c, (const float*)att1_c, Slabs{slabA, ksA, (long)B * NA, NA},
                                        w->attention_decoder_att_bias, w->attention_full_att_weight,
                                        w->attention_full_att_bias, Slabs{slabA + A, ksA, (long)B * NA, NA},
                                        w->f_beta_bias, alpha_out, (long)T * P, s.alpha_tm + rowT * P,
@@ -423,23 +461,23 @@ int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
                 } else {
                     SCN_TRY(attn_scores(cs, bt_, P, A, att1_c, Slabs{slabA, ksA, (long)B * NA, NA},
                                         w->attention_decoder_att_bias, w->attention_full_att_weight,
-                                        w->attention_full_att_bias, e_c, s.att2_all + rowT * A));
+                                        w->attention_full_att_bias, e_c, s.att2_all + rowT * A, bf));
                     hipEvent_t evc = g_profile >= 2 ? prof_begin(cs) : nullptr;   // per-launch timing of the dominant kernel
                     SCN_TRY(attn_context(cs, bt_, P, E, enc_c, e_c, Slabs{slabA + A, ksA, (long)B * NA, NA},
                                          w->f_beta_bias, alpha_out, (long)T * P, s.alpha_tm + rowT * P,
-                                         s.awe_all + rowT * E, s.gate_all + rowT * E, s.z_all + rowT * E));
+                                         s.awe_all + rowT * E, s.gate_all + rowT * E, s.z_all + rowT * E, bf));
                     prof_end(cs, evc, 2, 1);
                 }
                 const int ksC = pick(bt_, F4, E, 1);
-                SCN_TRY(skinny_gemm(cs, bt_, F4, E, 1, s.z_all + rowT * E, E, 0, w->decode_step_weight_ia + (long)M * F4,
-                                    F4, 0, slabC, F4, 0, (long)B * F4, ksC));
+                SCN_TRY(skinny_gemm(cs, bt_, F4, E, 1, s.z_all + rowT * E, E, 0, WaM, F4, 0, slabC, F4, 0, (long)B * F4, ksC,
+                                    bf));
                 pz = Slabs{slabC, ksC, (long)B * F4, F4};
             }
             SCN_TRY(scn_mix_fwd(cs, bt_, F4, pz, s.ex + rowT * F4, Slabs{slabA + colph, ksA, (long)B * NA, NA}, qx, qh,
                                 s.pa_all + rowT * F4, s.ph_all + rowT * F4, xcat));
             const int ksD = pick(bt_, D, 2 * F, 4);
-            SCN_TRY(skinny_gemm(cs, bt_, D, 2 * F, 4, xcat, 8 * F, 2 * F, f.WD, D, (long)2 * F * D, slabD, D, BD, 4 * BD,
-                                ksD));
+            SCN_TRY(skinny_gemm(cs, bt_, D, 2 * F, 4, xcat, 8 * F, 2 * F, WD, D, (long)2 * F * D, slabD, D, BD, 4 * BD,
+                                ksD, bf));
             SCN_TRY(lstm_fwd(cs, bt_, D, Slabs{slabD, ksD, 4 * BD, D}, BD, w->decode_step_bias_ih,
                              w->decode_step_bias_hh, c, s.gates_all + rowT * 4 * D, s.Cs + (rowT + B) * D,
                              s.Hs + (rowT + B) * D, s.tanhc_all + rowT * D));
@@ -524,6 +562,17 @@ int seq_bwd(hipStream_t st, hipStream_t wst, const scnattn_dims* dp, const scnat
         SCN_TRY(copy2d(st, E, D, w->f_beta_weight, D, k.WcatT + (long)F4 * D, D));
         SCN_TRY(copy2d(st, A, D, w->attention_decoder_att_weight, D, k.WcatT + (long)(F4 + E) * D, D));
     }
+    const bool bf = bf16_mode(d);
+    if (bf) {
+        SCN_TRY(f32_to_bf16(st, sz(4, D, 2 * F), k.WDb, k.WDbh));
+        SCN_TRY(f32_to_bf16(st, sz(NC, D), k.WcatT, k.WcatTh));
+        if (d.has_att) SCN_TRY(f32_to_bf16(st, sz(F4, E), k.WaTz, k.WaTzh));
+    }
+    const void* WDb = bf ? (const void*)k.WDbh : k.WDb;
+    const void* WcatT = bf ? (const void*)k.WcatTh : k.WcatT;
+    const void* WaTz = bf ? (const void*)k.WaTzh : k.WaTz;
+    const void* att1_s = (bf && d.has_att) ? (const void*)s.att1h : s.att1;     // the copies the forward pass streamed
+    const void* enc_s = (bf && d.has_att) ? (const void*)s.ench : enc;
     SCN_HIP(hipMemsetAsync(k.dc, 0, sizeof(float) * BD, st));
     SCN_HIP(hipMemsetAsync(k.dqx_acc, 0, sizeof(float) * B * F4, st));
     SCN_HIP(hipMemsetAsync(k.dqh_acc, 0, sizeof(float) * B * F4, st));
@@ -531,8 +580,8 @@ int seq_bwd(hipStream_t st, hipStream_t wst, const scnattn_dims* dp, const scnat
     // ---- reverse recurrence ----------------------------------------------------------------------
     hipEvent_t ev0 = prof_begin(st);
     SCN_TRY(run_chains(st, 1, B, [&](hipStream_t cs, int r0, int rmax) -> int {
-        const float* enc_c = enc + (long)r0 * (Q > 0 ? Q : P) * E;
-        const float* att1_c = d.has_att ? s.att1 + (long)r0 * P * A : nullptr;
+        const void* enc_c = eoff(enc_s, (long)r0 * (Q > 0 ? Q : P) * E, bf && d.has_att);
+        const void* att1_c = d.has_att ? eoff(att1_s, (long)r0 * P * A, bf) : nullptr;
         float* sDb = k.sDb + (long)r0 * 2 * F;
         float* sZ = d.has_att ? k.sZ + (long)r0 * E : nullptr;
         float* sH = k.sH + (long)r0 * D;
@@ -556,13 +605,13 @@ int seq_bwd(hipStream_t st, hipStream_t wst, const scnattn_dims* dp, const scnat
                              btn > 0 ? Slabs{sH, ksH, BD, D} : Slabs{nullptr, 0, 0, 0}, dc, s.gates_all + rowT * 4 * D,
                              s.Cs + rowT * D, s.tanhc_all + rowT * D, dr));
             const int ksDb = pick(bt_, 2 * F, D, 4);
-            SCN_TRY(skinny_gemm(cs, bt_, 2 * F, D, 4, dr, 4 * D, D, k.WDb, 2 * F, (long)D * 2 * F, sDb, 2 * F,
-                                (long)B * 2 * F, (long)4 * B * 2 * F, ksDb));
+            SCN_TRY(skinny_gemm(cs, bt_, 2 * F, D, 4, dr, 4 * D, D, WDb, 2 * F, (long)D * 2 * F, sDb, 2 * F,
+                                (long)B * 2 * F, (long)4 * B * 2 * F, ksDb, bf));
             SCN_TRY(scn_mix_bwd(cs, bt_, F4, Slabs{sDb, ksDb, (long)4 * B * 2 * F, 2 * F}, (long)B * 2 * F, qx, qh,
                                 s.pa_all + rowT * F4, s.ph_all + rowT * F4, dpx, dcat, NC, dqx_acc, dqh_acc));
             if (d.has_att) {
                 const int ksZ = pick(bt_, E, F4, 1);
-                SCN_TRY(skinny_gemm(cs, bt_, E, F4, 1, dpx, F4, 0, k.WaTz, E, 0, sZ, E, 0, (long)B * E, ksZ));
+                SCN_TRY(skinny_gemm(cs, bt_, E, F4, 1, dpx, F4, 0, WaTz, E, 0, sZ, E, 0, (long)B * E, ksZ, bf));
                 float* dawe = k.dawe_all + rowT * E;
                 SCN_TRY(gate_bwd(cs, bt_, E, Slabs{sZ, ksZ, (long)B * E, E}, s.awe_all + rowT * E,
                                  s.gate_all + rowT * E, dawe, dcat + F4, NC));
@@ -570,18 +619,18 @@ int seq_bwd(hipStream_t st, hipStream_t wst, const scnattn_dims* dp, const scnat
                 if (Q > 0) {
                     // Q dot products per image against x, folded onto the P pooled pixels inside softmax_bwd
                     float* dalphaq = k.dalphaq + (long)r0 * Q;
-                    SCN_TRY(attn_dalpha(cs, bt_, Q, E, enc_c, dawe, nullptr, 0, dalphaq));
+                    SCN_TRY(attn_dalpha(cs, bt_, Q, E, enc_c, dawe, nullptr, 0, dalphaq, bf));
                     SCN_TRY(attn_softmax_bwd_pooled(cs, bt_, P, A, att1_c, s.att2_all + rowT * A,
                                                     w->attention_full_att_weight, s.alpha_tm + rowT * P, pd, dalphaq, din,
-                                                    (long)T * P, k.de_all + rowT * P, dcat + F4 + E, NC));
+                                                    (long)T * P, k.de_all + rowT * P, dcat + F4 + E, NC, bf));
                 } else {
-                    SCN_TRY(attn_dalpha(cs, bt_, P, E, enc_c, dawe, din, (long)T * P, dalpha));
+                    SCN_TRY(attn_dalpha(cs, bt_, P, E, enc_c, dawe, din, (long)T * P, dalpha, bf));
                     SCN_TRY(attn_softmax_bwd(cs, bt_, P, A, att1_c, s.att2_all + rowT * A, w->attention_full_att_weight,
-                                             s.alpha_tm + rowT * P, dalpha, k.de_all + rowT * P, dcat + F4 + E, NC));
+                                             s.alpha_tm + rowT * P, dalpha, k.de_all + rowT * P, dcat + F4 + E, NC, bf));
                 }
             }
             ksH = pick(bt_, D, NC, 1);
-            SCN_TRY(skinny_gemm(cs, bt_, D, NC, 1, dcat, NC, 0, k.WcatT, D, 0, sH, D, 0, BD, ksH));
+            SCN_TRY(skinny_gemm(cs, bt_, D, NC, 1, dcat, NC, 0, WcatT, D, 0, sH, D, 0, BD, ksH, bf));
             tlast = t;
         }
         // d loss / d h0 for this chain's rows (d/d c0 is k.dc); every row decodes at t = 0
@@ -693,8 +742,8 @@ int seq_bwd(hipStream_t st, hipStream_t wst, const scnattn_dims* dp, const scnat
     }
     if (d.has_att) {
         int nblk = 0;
-        SCN_TRY(attn_datt1_post(st, B, P, A, T, dl_dev, s.att1, s.att2_all, k.de_all, w->attention_full_att_weight,
-                                k.datt1, k.dwpart, &nblk));
+        SCN_TRY(attn_datt1_post(st, B, P, A, T, dl_dev, att1_s, s.att2_all, k.de_all, w->attention_full_att_weight,
+                                k.datt1, k.dwpart, &nblk, bf));
         SCN_TRY(colsum(st, nblk, A + 1, k.dwpart, A + 1, k.dwtmp, 0.f));
         if (g->attention_full_att_weight)
             SCN_TRY(copy2d(st, 1, A, k.dwtmp, A + 1, g->attention_full_att_weight, A));

@@ -33,7 +33,7 @@ constexpr int NBW = KW / 8;   // 8-k blocks per wave per chunk
 constexpr int XLD = 33;       // padded leading dim of the reduction tile
 
 struct SkinnyArgs {
-    const float* X; const float* W; float* Y;
+    const float* X; const void* W; float* Y;
     long ldx, xg, ldw, wg, ldy, yg, yslab;
     int rows, N, K, kslice, groups, xvec;
 };
@@ -44,7 +44,8 @@ struct SkinnyArgs {
 // W[k0 + 4kk + c][n] for c = 0..3.  No LDS staging, no barrier before the MFMA chain.
 // NB = 8-k blocks per wave per chunk (compile-time so that every loop below is branch-free: a run-time
 // bound makes hipcc sink the loads of the optional blocks next to their MFMAs, each behind a vmcnt(0)).
-template <int NB, bool XVEC>
+// WBF: the weights are stored as bf16 (2-byte loads, widened in registers); fp32 MFMA and accumulation either way.
+template <int NB, bool XVEC, bool WBF>
 __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
     __shared__ float red[4][32 * XLD];
 
@@ -64,11 +65,13 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
     const bool rok = row < a.rows;
     // descriptors are built from wave-uniform values only (kernel args, blockIdx): rows >= kend of W and
     // rows >= a.rows of X are out of range and read as 0; columns / k beyond the tile get OOB_OFF.
-    const __amdgpu_buffer_rsrc_t wr = make_rsrc(a.W + (long)grp * a.wg, (unsigned)((long)kend * a.ldw * 4));
+    constexpr unsigned WB = WBF ? 2u : 4u;             // bytes per weight element
+    const __amdgpu_buffer_rsrc_t wr = make_rsrc(reinterpret_cast<const char*>(a.W) + (long)grp * a.wg * WB,
+                                                (unsigned)((long)kend * a.ldw * WB));
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.X + (long)grp * a.xg, (unsigned)((long)a.rows * a.ldx * 4));
-    const unsigned wcol = nok ? (unsigned)n * 4u : OOB_OFF;
+    const unsigned wcol = nok ? (unsigned)n * WB : OOB_OFF;
     const unsigned xrow = rok ? (unsigned)((long)row * a.ldx * 4) : OOB_OFF;
-    const unsigned ldw4 = (unsigned)a.ldw * 4u;
+    const unsigned ldw4 = (unsigned)a.ldw * WB;
 
     f32x16 acc;
 #pragma unroll
@@ -82,7 +85,10 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
         for (int j = 0; j < NB; ++j) {
             const unsigned k = (unsigned)(kw0 + 8 * j + 4 * kk);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) wf[j][c] = buf_load(wr, nok ? (k + c) * ldw4 + wcol : OOB_OFF);
+            for (int c = 0; c < 4; ++c) {
+                const unsigned off = nok ? (k + c) * ldw4 + wcol : OOB_OFF;
+                wf[j][c] = WBF ? bf16_to_f32(__builtin_amdgcn_raw_buffer_load_b16(wr, off, 0, 0)) : buf_load(wr, off);
+            }
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
@@ -138,12 +144,12 @@ int skinny_pick_ksplit(int rows, int N, int K, int groups) {
 }
 
 int skinny_gemm(hipStream_t st, int rows, int N, int K, int groups, const float* X, long ldx, long xg,
-                const float* W, long ldw, long wg, float* Y, long ldy, long yg, long yslab, int ksplit) {
+                const void* W, long ldw, long wg, float* Y, long ldy, long yg, long yslab, int ksplit, bool wbf) {
     if (rows <= 0 || N <= 0 || groups <= 0) return 0;
     SCN_ARG(X && W && Y, "skinny_gemm: null operand");
     SCN_ARG(K >= 1, "skinny_gemm: K must be >= 1");
     SCN_ARG(ksplit >= 1 && ksplit <= SCN_MAX_KSPLIT, "skinny_gemm: ksplit out of range");
-    SCN_ARG((long)K * ldw * 4 < 0x7fffffffL && (long)rows * ldx * 4 < 0x7fffffffL,
+    SCN_ARG((long)K * ldw * (wbf ? 2 : 4) < 0x7fffffffL && (long)rows * ldx * 4 < 0x7fffffffL,
             "skinny_gemm: operand exceeds the 2 GiB buffer-descriptor range");
     int per = cdiv(cdiv(K, ksplit), 4);      // k per wave
     per = (per + 7) & ~7;                    // whole 8-k blocks
@@ -155,8 +161,13 @@ int skinny_gemm(hipStream_t st, int rows, int N, int K, int groups, const float*
     dim3 grid(cdiv(N, 32) * groups, ksplit, cdiv(rows, 32)), block(256);
 #define SCN_SKINNY_CASE(NB_)                                                                     \
     case NB_:                                                                                     \
-        if (xvec) hipLaunchKernelGGL((skinny_kernel<NB_, true>), grid, block, 0, st, a);          \
-        else      hipLaunchKernelGGL((skinny_kernel<NB_, false>), grid, block, 0, st, a);         \
+        if (wbf) {                                                                                \
+            if (xvec) hipLaunchKernelGGL((skinny_kernel<NB_, true, true>), grid, block, 0, st, a);    \
+            else      hipLaunchKernelGGL((skinny_kernel<NB_, false, true>), grid, block, 0, st, a);   \
+        } else {                                                                                  \
+            if (xvec) hipLaunchKernelGGL((skinny_kernel<NB_, true, false>), grid, block, 0, st, a);   \
+            else      hipLaunchKernelGGL((skinny_kernel<NB_, false, false>), grid, block, 0, st, a);  \
+        }                                                                                         \
         break;
     switch (nb) {
         SCN_SKINNY_CASE(1) SCN_SKINNY_CASE(2) SCN_SKINNY_CASE(3) SCN_SKINNY_CASE(4)

@@ -60,6 +60,7 @@ def build_decoder(kind, cfg):
 class TrainStep:
     def __init__(self, kind="attention_scn", fine_tune_encoder=True, device="cuda", seed=1234, encoder=True,
                  bucket_mb=32, graph_encoder=False, tagger=False, force_reduce=False, encoder_dtype="f32",
+                 decoder_dtype="f32",
                  fused_loss=True, pooled_attention=True, **overrides):
         self.cfg = dict(DEFAULTS)
         self.cfg.update(overrides)
@@ -70,6 +71,12 @@ class TrainStep:
         # through the fused BatchNorm kernels, fp32 master weights/statistics); the decoder stays fp32.
         # This is BASELINE config 5's mixed-precision flavour, NOT the headline fp32 metric.
         self.encoder_bf16 = encoder_dtype == "bf16"
+        # decoder "bf16": the operands the recurrence streams every step (recurrent weights, att1, the trunk map) are
+        # read as bf16 copies made once per call (include/scnattn.h, option "decoder_bf16"); fp32 accumulate, fp32
+        # softmax / LSTM state / master weights / gradients.  A process-wide option of the library.
+        self.decoder_bf16 = decoder_dtype == "bf16"
+        if torch.device(device).type == "cuda":
+            SF.set_option("decoder_bf16", 1 if self.decoder_bf16 else 0)
         self.device = torch.device(device)
         torch.manual_seed(seed)  # same seed on every rank => identical initial weights
         self.decoder = build_decoder(kind, self.cfg).to(self.device)
