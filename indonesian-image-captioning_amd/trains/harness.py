@@ -112,6 +112,7 @@ class TrainStep:
             for r in self.reducers:
                 r.enabled = True
         self.decoder.train()
+        self.graphed = False         # make_graphed_callables patches the module's forward in place: no extra keywords then
         self.encoder_call = self.encoder
         if self.encoder is not None:
             self.encoder.train()   # reference quirk Q3: BN uses batch statistics even when frozen
@@ -122,6 +123,7 @@ class TrainStep:
                 cfg = self.cfg
                 sample = torch.randn(cfg["batch_size"], 3, cfg["image_size"], cfg["image_size"], device=self.device)
                 self.encoder_call = torch.cuda.make_graphed_callables(self.encoder, (sample,), num_warmup_iters=3)
+                self.graphed = True
 
     def loss_fn(self, scores, caps_sorted, decode_lengths, alphas, dl_dev=None):
         """trains/attention_scn.py:222-236.  On the GPU: one fused forward/backward pair on the unpacked
@@ -143,7 +145,7 @@ class TrainStep:
         explicitly and skips the pooling kernel and its 51 MB write."""
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.encoder_bf16):
             if self.encoder is not None:
-                if self.pooled_attention and self.encoder_call is self.encoder and not drop_in:
+                if self.pooled_attention and not self.graphed and not drop_in:
                     prepool = self.encoder(imgs, pooled=False)     # the decoder works on the 8x8 source map
                     encoder_out = None
                 else:
