@@ -178,6 +178,13 @@ int scnattn_skinny_gemm_bf16w(void* stream, int rows, int N, int K, int groups, 
                               const void* W_bf16, long ldw, long wg, float* Y, long ldy, long yg, long yslab,
                               int ksplit, int* ksplit_out);
 int scnattn_f32_to_bf16(void* stream, long n, const float* in, void* out);
+
+/* HIP streams with an explicit priority for hosts whose framework cannot create them (PyTorch exposes only "normal" and
+ * "high"): the weight-gradient / communication side streams of a train step are created at the LOWEST priority the
+ * device offers, so that the kernels of the critical path are dispatched first wherever both streams have work. */
+int scnattn_stream_priority_range(int* least, int* greatest);
+int scnattn_stream_create(int priority, void** out);
+int scnattn_stream_destroy(void* stream);
 /* models/attention.py:37-39 */
 int scnattn_attn_scores(void* stream, int rows, int P, int A, const float* att1, const float* att2, int nslab,
                         long slab_stride, long att2_ld, const float* dec_bias, const float* w, const float* b0,

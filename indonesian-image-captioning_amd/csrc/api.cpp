@@ -247,6 +247,27 @@ int scnattn_skinny_gemm_bf16w(void* stream, int rows, int N, int K, int groups, 
     return skinny_gemm(ST(stream), rows, N, K, groups, X, ldx, xg, W_bf16, ldw, wg, Y, ldy, yg, yslab, ksplit, true);
 }
 
+int scnattn_stream_priority_range(int* least, int* greatest) {
+    int lo = 0, hi = 0;
+    SCN_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    if (least) *least = lo;
+    if (greatest) *greatest = hi;
+    return 0;
+}
+
+int scnattn_stream_create(int priority, void** out) {
+    SCN_ARG(out, "stream_create: NULL");
+    hipStream_t s = nullptr;
+    SCN_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority));
+    *out = s;
+    return 0;
+}
+
+int scnattn_stream_destroy(void* stream) {
+    if (stream) SCN_HIP(hipStreamDestroy(ST(stream)));
+    return 0;
+}
+
 int scnattn_f32_to_bf16(void* stream, long n, const float* in, void* out) { return f32_to_bf16(ST(stream), n, in, out); }
 
 int scnattn_attn_scores(void* stream, int rows, int P, int A, const float* att1, const float* att2, int nslab,

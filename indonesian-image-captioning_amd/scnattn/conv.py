@@ -85,7 +85,26 @@ def conv3_choices():
     return {k: ("hip" if v else "miopen") for k, v in _c3_choice.items()}
 
 
-def _concurrent_stream(dev, attempts=8, beside=()):
+SIDE_PRIORITY = os.environ.get("SCNATTN_SIDE_PRIORITY", "default")     # "low": lowest stream priority the device offers
+
+
+def _new_stream(dev, low):
+    """PyTorch's stream pool knows two priorities (normal, high); HIP has a third, lower one.  "low": a raw HIP stream of
+    the lowest priority (include/scnattn.h scnattn_stream_create) wrapped as an ExternalStream."""
+    if low:
+        h = _lib.lib()
+        lo, hi = C.c_int(0), C.c_int(0)
+        _chk(h.scnattn_stream_priority_range(C.byref(lo), C.byref(hi)), "scnattn_stream_priority_range")
+        with torch.cuda.device(dev):
+            raw = C.c_void_p()
+            _chk(h.scnattn_stream_create(lo.value, C.byref(raw)), "scnattn_stream_create")
+        st = torch.cuda.ExternalStream(raw.value, device=dev)
+        st._scn_priority = (lo.value, hi.value)
+        return st
+    return torch.cuda.Stream(device=dev)
+
+
+def _concurrent_stream(dev, attempts=8, beside=(), low=None):
     """A stream whose kernels really run beside the current stream's.  HIP multiplexes its streams onto a few hardware
     queues (4 by default); two streams that land on the same queue are serialised, and which ones collide depends on
     how many streams the process created before (RCCL's, the allocator's, another module's).  Measured on MI355X: with
@@ -98,7 +117,7 @@ def _concurrent_stream(dev, attempts=8, beside=()):
     tried = []
     with torch.cuda.device(dev):
         for i in range(attempts):
-            cand = torch.cuda.Stream(device=dev)
+            cand = _new_stream(dev, SIDE_PRIORITY == "low" if low is None else low)
             tried.append(cand)                 # keep it referenced: the pool hands out a different stream next time
             with torch.cuda.stream(cand):
                 probe.add_(1.0)                # code object / allocator warm-up on the candidate
