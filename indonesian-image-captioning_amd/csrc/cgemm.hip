@@ -58,6 +58,7 @@ struct CArgs {
     int S, kper;                  // split-K
     float* ws;
     int mt, nt;                   // tile grid
+    int stagger;                  // start delay (x64 cycles) per residency round of workgroups, see g_cgemm_stagger
     // conv extras
     int gHi, gWi, gHo, gWo, gs;   // row gather (strided 1x1 convolution); gs == 0: none.  3x3: source / destination maps
     int c3c;                      // 3x3 modes: channels per tap of the gathered operand (Cin forward / wgrad, Cout dgrad)
@@ -116,6 +117,22 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int hh = lane >> 5, l31 = lane & 31;
+
+    // ---- optional start stagger (speed only) ---------------------------------------------------------------------
+    // All workgroups of a launch start together, so co-resident ones fill their rings, run their K loops and store
+    // their tiles in lock-step: the matrix pipe idles chip-wide during fills and stores.  Delaying the second / third
+    // workgroup a CU receives by a fraction of a tile time lets one workgroup's stores overlap another's MFMAs.
+    if (g.stagger > 0) {
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+        int rounds = min(lin >> 8, 2) * g.stagger;
+        while (rounds > 0) {
+            const int n = min(rounds, 127);
+            // s_sleep takes an immediate: 127 / 16 / 1 units compose any count
+            if (n == 127) { __builtin_amdgcn_s_sleep(127); rounds -= 127; }
+            else if (n >= 16) { __builtin_amdgcn_s_sleep(16); rounds -= 16; }
+            else { __builtin_amdgcn_s_sleep(1); rounds -= 1; }
+        }
+    }
 
     // ---- XCD-aware tile order (speed only): blocks b, b+8, b+16 ... share an XCD ---------------------------
     const int ntiles = g.mt * g.nt;
@@ -703,6 +720,7 @@ int g_cgemm_vec = 1;          // LDS-transposed 16-byte C stores when the output
 int g_cgemm_target = 512;     // aim for this many workgroups (tiles x splits) when the tile grid alone is < 256
 int g_cgemm_kmin = 128;       // at least this much K per split
 int g_cgemm_mi = 0;           // 0: pick the row tile (64 or 128) per shape; 1 / 2: force it (tuning)
+int g_cgemm_stagger = 0;      // start delay per residency round, in units of 64 cycles (experiment)
 
 bool cgemm_supported(bool tA, bool tB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                      long sA, long sB) {
@@ -824,6 +842,7 @@ int cgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.rowmask = rowmask;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = sA; g.sB = sB; g.sC = sC;
     g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta; g.S = S; g.kper = kper; g.ws = ws; g.mt = mt; g.nt = nt;
+    g.stagger = g_cgemm_stagger;
     if (ex) {
         g.gHi = ex->Hi; g.gWi = ex->Wi; g.gHo = ex->Ho; g.gWo = ex->Wo; g.gs = (gather || c3) ? ex->stride : 0;
         g.c3c = ex->c3c; g.src_rows = ex->c3_src_rows;
