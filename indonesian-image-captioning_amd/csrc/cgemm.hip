@@ -96,7 +96,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     else static_assert(N < 0, "unsupported count");
 }
 
-// MI: 32-row MFMA tiles per wave along m (block tile = 64*MI x 128).
+// MI: 32-row MFMA tiles per wave along m (block tile = 64*MI x 128, waves 2 x 2).
+// MI = 4 is a different WAVE LAYOUT, not a bigger register block: the four waves stack along m (4 x 1), each owning
+// one 32-row block of ALL the columns the tile has -- a 128 x 64 tile for outputs that are at most 64 wide (the
+// 64-channel maps of layer1).  With the 2 x 2 layout half of such a tile's MFMAs multiply zero columns.
 // A_MC / B_MC: operand stored with its m / n dimension contiguous ([K][M] / [K][N]); otherwise k contiguous.
 // PRO: 0 none, 1 relu(a*scale[k]+shift[k]) on a KC A operand, 2 relu(b*scale[n]+shift[n]) on a MC B operand.
 // EPI: 0 plain (alpha, beta, bias, rowmask), 1 plain store + column statistics.
@@ -110,12 +113,14 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 template <int MI, bool A_MC, bool B_MC, int PRO, int EPI, bool GATHER, bool VEC, int C3 = 0>
 __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
     __shared__ __attribute__((aligned(16))) float lds[NSTAGE * STAGE_F];
-    constexpr int TM = 64 * MI;
-    constexpr int ACH = MI;                            // A chunks (1 KiB LDS-DMA pieces) per wave per tile
+    constexpr bool W41 = (MI == 4);
+    constexpr int RB = W41 ? 1 : MI;                   // 32-row MFMA blocks per wave
+    constexpr int TM = W41 ? 128 : 64 * MI;
+    constexpr int ACH = TM / 64;                       // A chunks (1 KiB LDS-DMA pieces) per wave per tile
     constexpr int LPT = ACH + 2 + (PRO == 1 ? 1 : 0);  // LDS-DMA instructions per wave per tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = W41 ? wave : wave >> 1, wn = W41 ? 0 : wave & 1;
     const int hh = lane >> 5, l31 = lane & 31;
 
     // ---- optional start stagger (speed only) ---------------------------------------------------------------------
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
             a_ok[c] = grow < g.M;
             const long src = (GATHER ? gather_row(g, a_ok[c] ? grow : 0) : (long)grow) * g.lda + gsrc * 4;
             a_off[c] = (unsigned)(src * 4);
-        } else if (MI == 2) {
+        } else if (TM == 128) {
             const int col = m0 + 4 * (lane & 31);
             a_ok[c] = col < g.M;
             a_off[c] = (unsigned)(((long)(chunk * 2 + (lane >> 5)) * g.lda + col) * 4);
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
                 const int kk = k0 + 4 * ((lane & 3) ^ (((chunk * 16 + (lane >> 2)) >> 2) & 3));
                 va = (a_ok[c] && kk < Kend) ? a_off[c] + (unsigned)k0 * 4u : OOB_OFF;
             } else {
-                const int kr = k0 + (MI == 2 ? chunk * 2 + (lane >> 5) : chunk * 4 + (lane >> 4));
+                const int kr = k0 + (TM == 128 ? chunk * 2 + (lane >> 5) : chunk * 4 + (lane >> 4));
                 va = (a_ok[c] && kr < Kend) ? a_off[c] + (unsigned)((long)k0 * g.lda * 4) : OOB_OFF;
             }
             dma16(ars, sa + chunk * 256, va);
@@ -270,9 +275,9 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
         }
     };
 
-    f32x16 acc[MI][2];
+    f32x16 acc[RB][2];
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < RB; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -327,17 +332,17 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
         }
         const float* sa = lds + stage * STAGE_F;
         const float* sb = sa + TILE_F;
-        float a[MI][8], b[2][8];
+        float a[RB][8], b[2][8];
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
+        for (int i = 0; i < RB; ++i) {
             if (!A_MC) {
-                const int row = wm * 32 * MI + i * 32 + l31, sw = (row >> 2) & 3;
+                const int row = wm * 32 * RB + i * 32 + l31, sw = (row >> 2) & 3;
                 const f32x4 v0 = *reinterpret_cast<const f32x4*>(sa + row * 16 + (((2 * hh) ^ sw) << 2));
                 const f32x4 v1 = *reinterpret_cast<const f32x4*>(sa + row * 16 + (((2 * hh + 1) ^ sw) << 2));
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { a[i][q] = v0[q]; a[i][4 + q] = v1[q]; }
             } else {
-                const int col = wm * 32 * MI + i * 32 + l31;
+                const int col = wm * 32 * RB + i * 32 + l31;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) a[i][q] = sa[(8 * hh + q) * TM + col];
             }
@@ -365,7 +370,7 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
 #pragma unroll
         for (int q = 0; q < 8; ++q)
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < RB; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
@@ -405,12 +410,12 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
                 lw[mfma32_row(r, lane) * 64 + j * 32 + l31] = g.alpha * acc[i][j][r] + (j ? add1 : add0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // same wave wrote it: only the LDS counter drains
     };
-    const int mw0 = m0 + wm * 32 * MI;             // first row of this wave
+    const int mw0 = m0 + wm * 32 * RB;             // first row of this wave
 
     if (g.S > 1) {   // split-K: raw alpha-scaled partial tile; the reduce kernels apply the epilogue
         if constexpr (VEC) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
+            for (int i = 0; i < RB; ++i) {
                 dump_half(i, 0.f, 0.f);
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
@@ -421,7 +426,7 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < RB; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int n = n0 + wn * 64 + j * 32 + l31;
@@ -446,7 +451,7 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
             if (g.bias && n < g.N) bv[j] = g.bias[n];
         }
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
+        for (int i = 0; i < RB; ++i) {
             f32x4 cv[8];
             float mk[8];
             if (use_c) {
@@ -487,7 +492,7 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
             const float sft = (g.stat_shift && n < g.N) ? g.stat_shift[n] : 0.f;
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < RB; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = mw0 + i * 32 + mfma32_row(r, lane);
@@ -517,8 +522,18 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
                 p[g.N] = colsum[1 * TN + tid] + colsum[3 * TN + tid];
             }
         }
+        if (W41) {     // waves (0,1) form the tile's first 64-row statistics block, waves (2,3) its second
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int blk = tid >> 6, col = tid & 63;
+            if (tid < 128 && n0 + col < g.N && m0 + blk * 64 < g.M) {
+                float* p = g.stat_partial + ((long)(tm * 2 + blk) * 2) * g.N + n0 + col;
+                p[0] = colsum[((2 * blk) * 2 + 0) * TN + col] + colsum[((2 * blk + 1) * 2 + 0) * TN + col];
+                p[g.N] = colsum[((2 * blk) * 2 + 1) * TN + col] + colsum[((2 * blk + 1) * 2 + 1) * TN + col];
+            }
+        }
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
+        for (int i = 0; i < RB; ++i) {
             dump_half(i, 0.f, 0.f);
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
@@ -536,7 +551,7 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
         const __amdgpu_buffer_rsrc_t cr = make_rsrc(C, use_c ? (unsigned)(((long)(g.M - 1) * g.ldc + g.N) * 4) : 0u);
         const __amdgpu_buffer_rsrc_t mr = make_rsrc(g.rowmask, use_m ? (unsigned)g.M * 4u : 0u);
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < RB; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int n = n0 + wn * 64 + j * 32 + l31;
@@ -720,6 +735,7 @@ int g_cgemm_vec = 1;          // LDS-transposed 16-byte C stores when the output
 int g_cgemm_target = 512;     // aim for this many workgroups (tiles x splits) when the tile grid alone is < 256
 int g_cgemm_kmin = 128;       // at least this much K per split
 int g_cgemm_mi = 0;           // 0: pick the row tile (64 or 128) per shape; 1 / 2: force it (tuning)
+int g_cgemm_w41 = 1;          // 1: outputs at most 64 wide take the 128 x 64 tile with the 4 x 1 wave layout
 int g_cgemm_stagger = 0;      // start delay per residency round, in units of 64 cycles (experiment)
 
 bool cgemm_supported(bool tA, bool tB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
@@ -812,9 +828,11 @@ int cgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
     const int nt = cdiv(N, TN);
     int mi = 2;
     if ((long)cdiv(M, 128) * nt * batch < 256 && M > 64 && c3 != 1 && c3 != 2) mi = 1;
+    if (N <= 64 && M >= 128 && g_cgemm_w41 && c3 != 3) mi = 4;     // 128 x 64 tiles, waves 4 x 1 (layer1's 64-channel maps)
     if (g_cgemm_mi == 1 || g_cgemm_mi == 2) mi = g_cgemm_mi;
     if (ex && ex->force_mi > 0) mi = ex->force_mi;
-    const int tmrows = 64 * mi, mt = cdiv(M, tmrows);
+    SCN_ARG(mi == 1 || mi == 2 || (mi == 4 && N <= 64 && c3 != 3), "cgemm: bad tile selector (4 needs N <= 64)");
+    const int tmrows = mi == 4 ? 128 : 64 * mi, mt = cdiv(M, tmrows);
     const long tiles = (long)mt * nt * batch;
     int S = 1;
     if (ws && tiles < 224 && K >= 2 * g_cgemm_kmin) {
@@ -855,8 +873,11 @@ int cgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
     const int kepi = (S > 1 || epi == 2) ? 0 : epi;
     if (c3) {
         SCN_ARG(vec, "cgemm: 3x3 mode needs 16-byte row stores");
-        if (mi == 2) SCN_TRY(launch_conv3<2>(st, grid, g, c3, kepi)); else SCN_TRY(launch_conv3<1>(st, grid, g, c3, kepi));
-    } else if (mi == 2) SCN_TRY(launch_layout<2>(st, grid, g, tA, tB, pro, kepi, gather, vec));
+        if (mi == 4) SCN_TRY(launch_conv3<4>(st, grid, g, c3, kepi));
+        else if (mi == 2) SCN_TRY(launch_conv3<2>(st, grid, g, c3, kepi));
+        else SCN_TRY(launch_conv3<1>(st, grid, g, c3, kepi));
+    } else if (mi == 4) SCN_TRY(launch_layout<4>(st, grid, g, tA, tB, pro, kepi, gather, vec));
+    else if (mi == 2) SCN_TRY(launch_layout<2>(st, grid, g, tA, tB, pro, kepi, gather, vec));
     else SCN_TRY(launch_layout<1>(st, grid, g, tA, tB, pro, kepi, gather, vec));
     SCN_LAUNCH_CHECK();
     if (S > 1 || epi == 2) {

@@ -867,3 +867,64 @@ def test_bf16_storage_attention_gradients_with_unambiguous_relu_mask(dev):
                  tol_out=5e-2, tol_grad=5e-2)
     finally:
         SF.set_option("decoder_bf16", 0)
+
+
+# ------------------------------------------------------------------------------------------------
+# E1: gradients of the WHOLE ResNet-152 trunk (fused Bottleneck path) against fp64
+# ------------------------------------------------------------------------------------------------
+def test_encoder_gradients_are_as_close_to_fp64_as_cpu_fp32_is(dev):
+    """EncoderCaption forward + backward through all 50 fused Bottleneck blocks on the GPU, against the same definition
+    run in fp64 on the CPU.  A randomly initialised 152-layer trunk in training mode (batch statistics) is badly
+    conditioned: torch's OWN fp32 CPU gradients are ~1e-1 from fp64 (ReLU-mask flips compounded through ~150
+    BatchNorm layers; measured 9.8e-2 over all fine-tuned parameters).  So fp64 is the anchor and CPU fp32 the
+    yardstick: per stage (layer2, layer3, layer4) and over all parameters the GPU's distance to fp64 must not exceed the
+    CPU fp32's by more than 25 % (measured: 9.66e-2 vs 9.76e-2 globally, medians within 5 %).  The block-level test
+    (test_fused_bottleneck_vs_fp64) holds single blocks to 1e-4; this one shows nothing is lost in composition.
+    Parity against the reference's torchvision stays unpinned."""
+    import copy
+    import statistics
+    from models.encoders.caption import EncoderCaption
+    from oracle import scnattn_ref as R
+    torch.manual_seed(0)
+    enc = EncoderCaption(channels_last=True)
+    enc.fine_tune(True)
+    enc.train()
+    x = torch.randn(4, 3, 160, 160)
+
+    def run_cpu(dt):
+        m = copy.deepcopy(enc).to(dt)
+        y = R.pool_permute(m.resnet(x.to(dt)), 14)
+        torch.manual_seed(1)
+        w = torch.randn(y.shape).to(dt)
+        (y * w).sum().backward()
+        return y.detach(), {k: p.grad.detach() for k, p in m.named_parameters() if p.grad is not None}
+
+    y64, g64 = run_cpu(torch.float64)
+    y32, g32 = run_cpu(torch.float32)
+    g = copy.deepcopy(enc).to(dev)
+    yg = g(x.to(dev))
+    torch.manual_seed(1)
+    w = torch.randn(y64.shape)
+    (yg * w.to(dev)).sum().backward()
+    gg = {k: p.grad.detach().cpu() for k, p in g.named_parameters() if p.grad is not None}
+    assert set(gg) == set(g64)
+
+    def rl2(a, b):
+        return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-300)).item()
+
+    ey_gpu, ey_cpu = rl2(yg.cpu(), y64), rl2(y32, y64)
+    assert ey_gpu <= max(5e-3, 1.5 * ey_cpu), (ey_gpu, ey_cpu)
+    eg = {k: rl2(gg[k], g64[k]) for k in g64}
+    ec = {k: rl2(g32[k], g64[k]) for k in g64}
+    lines = ["encoder_out: gpu %.3e cpu-fp32 %.3e (vs fp64)" % (ey_gpu, ey_cpu)]
+    for stage in ("resnet.5", "resnet.6", "resnet.7"):
+        ks = [k for k in g64 if k.startswith(stage)]
+        mg, mc = statistics.median(eg[k] for k in ks), statistics.median(ec[k] for k in ks)
+        lines.append("%s (%d tensors): median rel-l2 to fp64  gpu %.3e  cpu-fp32 %.3e" % (stage, len(ks), mg, mc))
+        assert mg <= 1.25 * mc + 1e-3, (stage, mg, mc)
+    cat = lambda d: torch.cat([d[k].flatten().double() for k in g64])
+    a64 = cat(g64)
+    tg, tc = ((cat(gg) - a64).norm() / a64.norm()).item(), ((cat(g32) - a64).norm() / a64.norm()).item()
+    lines.append("all fine-tuned parameters: gpu %.3e  cpu-fp32 %.3e" % (tg, tc))
+    _report(lines, "whole ResNet-152 trunk, gradients vs fp64 (CPU fp32 as the yardstick)")
+    assert tg <= 1.25 * tc + 1e-3, (tg, tc)
