@@ -928,3 +928,119 @@ def test_encoder_gradients_are_as_close_to_fp64_as_cpu_fp32_is(dev):
     lines.append("all fine-tuned parameters: gpu %.3e  cpu-fp32 %.3e" % (tg, tc))
     _report(lines, "whole ResNet-152 trunk, gradients vs fp64 (CPU fp32 as the yardstick)")
     assert tg <= 1.25 * tc + 1e-3, (tg, tc)
+
+
+# ------------------------------------------------------------------------------------------------
+# L1/L3: the reference's literal train-loop body with STOCK torch.optim.Adam on the drop-in modules
+# ------------------------------------------------------------------------------------------------
+def test_reference_loop_body_with_stock_adam(dev):
+    """trains/attention_scn.py:213-252 verbatim on the drop-in modules -- encoder(imgs), decoder(encoder_out, ...),
+    pack_padded_sequence + CrossEntropyLoss + the alpha regulariser, zero_grad, backward, clip_gradient, step of two
+    STOCK torch.optim.Adam optimizers, two steps.
+    (1) Run twice, with the weight gradients on the side stream (default) and with everything on the main stream:
+        identical kernels on identical operands, so every gradient (read on the main stream right after backward(), no
+        synchronize) and every parameter after two steps must agree -- bit for bit in the decoder, to the 1e-7-level
+        noise of MIOpen's atomic kernels in the trunk.  A gradient read before the side stream finished, or written to
+        after autograd stored it, would be an O(1) error.
+    (2) Against the harness path (prepool hand-over, fused loss, FusedClampAdam over flat buffers): same second-step
+        loss to 2e-3 and parameters within the 2 * steps * lr an Adam trajectory can differ by (Adam normalises the
+        step, so near-zero gradients of either sign move a weight by +-lr; the randomly initialised trunk is badly
+        conditioned, see test_encoder_gradients_are_as_close_to_fp64_as_cpu_fp32_is)."""
+    import copy
+    from torch.nn.utils.rnn import pack_padded_sequence
+    from models.encoders.caption import EncoderCaption
+    from models.decoders.attention_scn import AttentionSCN
+    from utils.optimizer import clip_gradient, FusedClampAdam
+    from scnattn import functional as SF
+    from scnattn import conv as SC
+    torch.manual_seed(5)
+    B, V, L, S = 6, 200, 10, 64
+    enc0 = EncoderCaption(channels_last=True).to(dev)
+    enc0.fine_tune(True)
+    dec0 = AttentionSCN(64, 64, 64, 64, S, V, dropout=0.5).to(dev)
+    g = torch.Generator().manual_seed(9)
+    imgs = torch.randn(B, 3, 96, 96, generator=g).to(dev)
+    tags = torch.rand(B, S, generator=g).to(dev)
+    lens = torch.randint(4, L + 1, (B,), generator=g)
+    caps = _synthetic_caps(B, V, L, lens, g).to(dev)
+    caplens = lens.unsqueeze(1).to(dev)
+    T = int(lens.max()) - 1
+    masks = [((torch.rand(B, T, 64, generator=g) > 0.5).float() * 2.0).to(dev) for _ in range(2)]
+    criterion = torch.nn.CrossEntropyLoss().to(dev)
+
+    def reference_loop(side):
+        saved = SC.SIDE_WGRAD
+        SC.SIDE_WGRAD = side
+        try:
+            enc, dec = copy.deepcopy(enc0).train(), copy.deepcopy(dec0).train()
+            dec_opt = torch.optim.Adam(params=filter(lambda p: p.requires_grad, dec.parameters()), lr=4e-4)
+            enc_opt = torch.optim.Adam(params=filter(lambda p: p.requires_grad, enc.parameters()), lr=1e-4)
+            first = None
+            for step in range(2):
+                dec.drop_mask_override = masks[step]
+                encoder_out = enc(imgs)
+                scores, caps_sorted, decode_lengths, alphas, sort_ind = dec(encoder_out, tags, caps, caplens)
+                targets = caps_sorted[:, 1:]
+                scores = pack_padded_sequence(scores, decode_lengths, batch_first=True).data
+                targets = pack_padded_sequence(targets, decode_lengths, batch_first=True).data
+                loss = criterion(scores, targets)
+                loss = loss + 1.0 * ((1. - alphas.sum(dim=1)) ** 2).mean()
+                dec_opt.zero_grad()
+                enc_opt.zero_grad()
+                loss.backward()
+                if first is None:        # main stream, right after backward(), no synchronize
+                    first = {k: p.grad.clone() for k, p in list(dec.named_parameters()) + list(enc.named_parameters())
+                             if p.grad is not None}
+                clip_gradient(dec_opt, 5.)
+                clip_gradient(enc_opt, 5.)
+                dec_opt.step()
+                enc_opt.step()
+            params = {k: p.detach().clone() for k, p in list(dec.named_parameters()) + list(enc.named_parameters())}
+            return first, params, loss.detach()
+        finally:
+            SC.SIDE_WGRAD = saved
+
+    g_side, p_side, loss_side = reference_loop(True)
+    g_main, p_main, loss_main = reference_loop(False)
+    assert len(g_side) == len(g_main) and len(g_side) > 300
+    # Not torch.equal: MIOpen's kernels for the 3x3 weight gradients and the strided 3x3 d-input sum with atomics, so
+    # two runs differ in the last bits (1e-7 relative) wherever such a kernel is upstream.  An incomplete or overwritten
+    # gradient is an O(1) error.  The decoder's gradients have no library kernel upstream of them: bit-identical.
+    worst_g = 0.0
+    for k in g_main:
+        if k in dict(dec0.named_parameters()):
+            assert torch.equal(g_side[k], g_main[k]), "decoder gradient %s differs between the two runs" % k
+        e = rel_err(g_side[k], g_main[k]) if float(g_main[k].abs().max()) > 0 else 0.0
+        worst_g = max(worst_g, e)
+        assert e <= 1e-4, "gradient of %s differs between side-stream and main-stream runs: %.3e" % (k, e)
+    for k in p_main:      # Adam normalises its step: elements whose gradient is at noise level move by +-lr in either run
+        err = (p_side[k] - p_main[k]).abs().max().item()
+        assert err <= 2 * 2 * 4e-4 * 1.01, "parameter %s differs after two steps: %.3e" % (k, err)
+    _ok(loss_side, loss_main, 1e-4, "second-step loss of the two runs")
+    # ---- the harness path -------------------------------------------------------------------------------------------
+    enc_b, dec_b = copy.deepcopy(enc0).train(), copy.deepcopy(dec0).train()
+    dec_fo = FusedClampAdam(filter(lambda p: p.requires_grad, dec_b.parameters()), lr=4e-4, grad_clip=5.)
+    enc_fo = FusedClampAdam(filter(lambda p: p.requires_grad, enc_b.parameters()), lr=1e-4, grad_clip=5.)
+    for step in range(2):
+        dec_b.drop_mask_override = masks[step]
+        prepool = enc_b(imgs, pooled=False)
+        scores, caps_sorted, decode_lengths, alphas, sort_ind = dec_b(None, tags, caps, caplens, prepool=prepool,
+                                                                        pool_size=enc_b.enc_image_size)
+        dl_dev = (caplens.reshape(-1)[sort_ind] - 1).to(torch.int32)
+        loss_b = SF.caption_loss(scores, caps_sorted, decode_lengths, alphas, 1.0, dl_dev)
+        dec_fo.zero_grad()
+        enc_fo.zero_grad()
+        loss_b.backward()
+        dec_fo.step()
+        enc_fo.step()
+    _ok(loss_b, loss_side, 2e-3, "second-step loss, harness path vs reference loop body")
+    worst = 0.0
+    for k, pb in list(dec_b.named_parameters()) + list(enc_b.named_parameters()):
+        err = (p_side[k] - pb.detach()).abs().max().item()
+        worst = max(worst, err)
+        lr = 4e-4 if any(k == kd for kd, _ in dec_b.named_parameters()) else 1e-4
+        assert err <= 2 * 2 * lr * 1.01, "%s: abs err %.3e after two steps" % (k, err)
+    _report(["side-stream vs main-stream runs of the reference loop body: %d gradient tensors, worst rel err %.3e"
+             % (len(g_main), worst_g), "reference loop body vs harness path: second-step loss rel err %.3e, max abs parameter "
+             "difference %.3e" % (rel_err(loss_b, loss_side), worst)],
+            "reference loop body with stock torch.optim.Adam")

@@ -285,8 +285,33 @@ def stagger():
         print("%-9s | %s | %s" % (name, fmt(f), fmt(d)), flush=True)
 
 
+def sweep3():
+    """3x3 forward (with the statistics epilogue, as the block issues it) and dgrad: row tile x split-K factor."""
+    combos = [(2, 4), (2, 3), (2, 2), (2, 1), (1, 4), (1, 3), (1, 2), (1, 1)]
+    print("3x3 (mi,S): " + " ".join("%9s" % (c,) for c in combos) + " | policy")
+    for name, H, Cin in [("l2", 32, 128), ("l3", 16, 256), ("l4", 8, 512)]:
+        N, Cout = 32, Cin
+        x = torch.randn(N, Cin, H, H, device=dev).contiguous(memory_format=torch.channels_last)
+        w = (0.1 * torch.randn(Cout, Cin, 3, 3, device=dev)).contiguous(memory_format=torch.channels_last)
+        dy = torch.randn(N, Cout, H, H, device=dev).contiguous(memory_format=torch.channels_last)
+        y = torch.empty(N * H * H, Cout, device=dev); dx = torch.empty_like(x)
+        part = torch.empty(lib().scnattn_cgemm_row_tiles(N * H * H), 2, Cout, device=dev)
+        for kind in ("fwd+stats", "dgrad"):
+            ts = []
+            for mi, S in combos + [(0, 0)]:
+                ex = ConvExtra(force_mi=mi, force_split=S, epi=1 if kind != "dgrad" else 0, stat_partial=part.data_ptr())
+                if kind == "dgrad":
+                    fn = lambda: call("scnattn_conv3x3_dgrad", stream_of(x), N, H, H, Cin, Cout, ptr(dy), ptr(w), ptr(dx), C.byref(ex), ptr(WS), WS.numel())
+                else:
+                    fn = lambda: call("scnattn_conv3x3_fwd", stream_of(x), N, H, H, Cin, Cout, 1, ptr(x), ptr(w), ptr(y), C.byref(ex), ptr(WS), WS.numel())
+                ts.append(t_us(fn))
+            print("%-3s %-9s " % (name, kind) + " ".join("%9.1f" % t for t in ts[:-1]) + " | %6.1f" % ts[-1], flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what == "sweep3":
+        sweep3()
     if what == "stagger":
         stagger()
     if what in ("check", "all"):
