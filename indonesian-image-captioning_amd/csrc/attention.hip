@@ -49,6 +49,29 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(int rows, int P, int A
     float* ws = sm + A4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, p0 = blockIdx.x * PC;
+    // each wave: 4 pixel rows, independent accumulators (4 x 16 B loads in flight per lane)
+    const ET* rowp[4];
+    bool ok[4];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = p0 + wave * 4 + j;
+        ok[j] = p < P;
+        rowp[j] = att1 + ((long)b * P + (ok[j] ? p : P - 1)) * A;
+    }
+    // The att1 rows do not depend on att2: with A <= 512 a lane's whole share of them (2 x 4 loads) goes in flight
+    // BEFORE the att2 / w staging below, so the kernel pays one memory round trip, not two in a row.
+    const bool early = VEC && A <= 512;
+    f32x4 pre[2][4];
+    if (early) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int a = min(lane * 4 + 256 * it, A - 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pre[it][j] = ld4(rowp[j] + a);
+        }
+        __builtin_amdgcn_sched_barrier(0);      // keep hipcc from sinking the loads below the staging loop
+    }
     for (int a = tid; a < A4; a += 256) {
         float v = 0.f, wv = 0.f;
         if (a < A) {
@@ -60,17 +83,20 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(int rows, int P, int A
         ws[a] = wv;
     }
     __syncthreads();
-    // each wave: 4 pixel rows, independent accumulators (4 x 16 B loads in flight per lane)
-    const ET* rowp[4];
-    bool ok[4];
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (early) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int p = p0 + wave * 4 + j;
-        ok[j] = p < P;
-        rowp[j] = att1 + ((long)b * P + (ok[j] ? p : P - 1)) * A;
-    }
-    if (VEC) {
+        for (int it = 0; it < 2; ++it) {
+            const int a = lane * 4 + 256 * it;
+            if (a < A) {
+                const f32x4 s2 = *reinterpret_cast<const f32x4*>(att2s + a);
+                const f32x4 ww = *reinterpret_cast<const f32x4*>(ws + a);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[j] = fmaf(fmaxf(pre[it][j][c] + s2[c], 0.f), ww[c], acc[j]);
+            }
+        }
+    } else if (VEC) {
         for (int a = lane * 4; a < A; a += 256) {
             const f32x4 s2 = *reinterpret_cast<const f32x4*>(att2s + a);
             const f32x4 ww = *reinterpret_cast<const f32x4*>(ws + a);
@@ -616,6 +642,17 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(int rows, int P, 
     float* des = red + 16;         // [P]
     const int tid = threadIdx.x;
     const int b = blockIdx.y, a0 = blockIdx.x * 64;
+    // The first batch of att1 rows depends on nothing the prologue computes: in flight before it (the softmax-backward
+    // prologue is two block reductions deep), the next batch is requested while the current one is consumed.
+    const ET* const base0 = att1 + (long)b * P * A;
+    const int grp0 = tid >> 4, a_first = a0 + (tid & 15) * 4;
+    f32x4 vpre[4];
+    if (VEC) {
+        const int ac0 = min(a_first, A - 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vpre[j] = ld4(base0 + (long)min(grp0 + 16 * j, P - 1) * A + ac0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     float dot = 0.f;
     if (dt.tap_idx) {              // d alpha[p] = sum_k tap_w[p][k] * d alphaq[tap_idx[p][k]] (+ upstream d alphas)
         float* dq = part;          // [Q] staged first: the gather then needs no dependent global load
@@ -656,19 +693,30 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(int rows, int P, 
     if (VEC) {
         const int ac = min(a, A - 4);
         const bool aok = a < A;
+        f32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = vpre[j];
         for (int p = grp; p < P; p += 64) {
-            f32x4 v[4];
+            f32x4 nv[4];
             float d[4];
+            const int pn = p + 64;
+            if (pn < P) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) nv[j] = ld4(base + (long)min(pn + 16 * j, P - 1) * A + ac);
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int pp = p + 16 * j;
-                v[j] = ld4(base + (long)min(pp, P - 1) * A + ac);
                 d[j] = (pp < P && aok) ? des[min(pp, P - 1)] : 0.f;
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[c] += (v[j][c] + s2[c] > 0.f) ? d[j] : 0.f;
+            if (pn < P) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = nv[j];
+            }
         }
     } else {
         for (int p = grp; p < P; p += 16) {
