@@ -1003,13 +1003,11 @@ def test_reference_loop_body_with_stock_adam(dev):
     g_side, p_side, loss_side = reference_loop(True)
     g_main, p_main, loss_main = reference_loop(False)
     assert len(g_side) == len(g_main) and len(g_side) > 300
-    # Not torch.equal: MIOpen's kernels for the 3x3 weight gradients and the strided 3x3 d-input sum with atomics, so
-    # two runs differ in the last bits (1e-7 relative) wherever such a kernel is upstream.  An incomplete or overwritten
-    # gradient is an O(1) error.  The decoder's gradients have no library kernel upstream of them: bit-identical.
+    # Not torch.equal: MIOpen's kernels (3x3 weight gradients, strided 3x3 d-input, and whichever forward solver its
+    # find step picked in this process) sum with atomics, so two runs differ in the last bits (1e-7 .. 1e-5 relative)
+    # wherever such a kernel is upstream.  An incomplete or overwritten gradient is an O(1) error.
     worst_g = 0.0
     for k in g_main:
-        if k in dict(dec0.named_parameters()):
-            assert torch.equal(g_side[k], g_main[k]), "decoder gradient %s differs between the two runs" % k
         e = rel_err(g_side[k], g_main[k]) if float(g_main[k].abs().max()) > 0 else 0.0
         worst_g = max(worst_g, e)
         assert e <= 1e-4, "gradient of %s differs between side-stream and main-stream runs: %.3e" % (k, e)
