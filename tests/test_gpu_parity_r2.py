@@ -1002,15 +1002,20 @@ def test_reference_loop_body_with_stock_adam(dev):
 
     g_side, p_side, loss_side = reference_loop(True)
     g_main, p_main, loss_main = reference_loop(False)
+    g_again, _, _ = reference_loop(False)      # the library's own run-to-run noise, with no second stream anywhere
     assert len(g_side) == len(g_main) and len(g_side) > 300
     # Not torch.equal: MIOpen's kernels (3x3 weight gradients, strided 3x3 d-input, and whichever forward solver its
     # find step picked in this process) sum with atomics, so two runs differ in the last bits (1e-7 .. 1e-5 relative)
     # wherever such a kernel is upstream.  An incomplete or overwritten gradient is an O(1) error.
-    worst_g = 0.0
+    worst_g = worst_noise = 0.0
     for k in g_main:
         e = rel_err(g_side[k], g_main[k]) if float(g_main[k].abs().max()) > 0 else 0.0
         worst_g = max(worst_g, e)
         assert e <= 1e-4, "gradient of %s differs between side-stream and main-stream runs: %.3e" % (k, e)
+        noise = rel_err(g_again[k], g_main[k]) if float(g_main[k].abs().max()) > 0 else 0.0
+        worst_noise = max(worst_noise, noise)
+    # ... and it is the library's noise, not the second stream's: two main-stream-only runs differ just as much
+    assert worst_g <= 10 * worst_noise + 1e-6, (worst_g, worst_noise)
     for k in p_main:      # Adam normalises its step: elements whose gradient is at noise level move by +-lr in either run
         err = (p_side[k] - p_main[k]).abs().max().item()
         assert err <= 2 * 2 * 4e-4 * 1.01, "parameter %s differs after two steps: %.3e" % (k, err)
@@ -1038,7 +1043,7 @@ def test_reference_loop_body_with_stock_adam(dev):
         worst = max(worst, err)
         lr = 4e-4 if any(k == kd for kd, _ in dec_b.named_parameters()) else 1e-4
         assert err <= 2 * 2 * lr * 1.01, "%s: abs err %.3e after two steps" % (k, err)
-    _report(["side-stream vs main-stream runs of the reference loop body: %d gradient tensors, worst rel err %.3e"
-             % (len(g_main), worst_g), "reference loop body vs harness path: second-step loss rel err %.3e, max abs parameter "
+    _report(["side-stream vs main-stream runs of the reference loop body: %d gradient tensors, worst rel err %.3e "
+             "(two main-stream-only runs: %.3e)" % (len(g_main), worst_g, worst_noise), "reference loop body vs harness path: second-step loss rel err %.3e, max abs parameter "
              "difference %.3e" % (rel_err(loss_b, loss_side), worst)],
             "reference loop body with stock torch.optim.Adam")
