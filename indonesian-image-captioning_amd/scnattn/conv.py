@@ -414,34 +414,34 @@ class _BottleneckFn(torch.autograd.Function):
         # ---- conv2 (MIOpen) -------------------------------------------------------------------------------------
         dz2_4, a1_4 = _as4d(dz2, N, Ho, Wo), _as4d(a1, N, Hi, Wi)
         dw2 = None
-        if need[5] and side:
+        if need[5]:       # weight gradient: side stream when there is one, the same kernel on the main stream otherwise
             if CONV3_WGRAD == "hip" and p % 128 == 0 and w2.is_contiguous(memory_format=torch.channels_last):
                 dw2 = torch.empty_like(w2)
-                sw = side.fork(main, dz2, a1, dw2)
+                sw, wsw = (side.fork(main, dz2, a1, dw2), side.ws) if side else (st, ws)
                 _chk(h.scnattn_conv3x3_wgrad(sw, N, Hi, Wi, p, p, s, dz2.data_ptr(), a1.data_ptr(), dw2.data_ptr(),
-                                             side.ws.data_ptr(), side.ws.numel()), "scnattn_conv3x3_wgrad")
-            else:
+                                             wsw.data_ptr(), wsw.numel()), "scnattn_conv3x3_wgrad")
+            elif side:
                 side.fork(main, dz2, a1)
                 with torch.cuda.stream(side.stream):
                     _, dw2, _ = torch.ops.aten.convolution_backward(dz2_4, a1_4, w2, None, [s, s], [1, 1], [1, 1], False,
                                                                     [0, 0], 1, [False, True, False])
-            c3ok = s == 1 and p % 16 == 0 and w2.is_contiguous(memory_format=torch.channels_last)
+            else:
+                _, dw2, _ = torch.ops.aten.convolution_backward(dz2_4, a1_4, w2, None, [s, s], [1, 1], [1, 1], False,
+                                                                [0, 0], 1, [False, True, False])
+        c3ok = s == 1 and p % 16 == 0 and w2.is_contiguous(memory_format=torch.channels_last)
 
-            def hip_dgrad():
-                d = torch.empty((Rin, p), **f32)
-                _chk(h.scnattn_conv3x3_dgrad(st, N, Hi, Wi, p, p, dz2.data_ptr(), w2.data_ptr(), d.data_ptr(), None,
-                                             ws.data_ptr(), ws.numel()), "scnattn_conv3x3_dgrad")
-                return _as4d(d, N, Hi, Wi)
+        def hip_dgrad():
+            d = torch.empty((Rin, p), **f32)
+            _chk(h.scnattn_conv3x3_dgrad(st, N, Hi, Wi, p, p, dz2.data_ptr(), w2.data_ptr(), d.data_ptr(), None,
+                                         ws.data_ptr(), ws.numel()), "scnattn_conv3x3_dgrad")
+            return _as4d(d, N, Hi, Wi)
 
-            def miopen_dgrad():
-                return torch.ops.aten.convolution_backward(dz2_4, a1_4, w2, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1,
-                                                           [True, False, False])[0]
+        def miopen_dgrad():
+            return torch.ops.aten.convolution_backward(dz2_4, a1_4, w2, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1,
+                                                       [True, False, False])[0]
 
-            da1_4 = hip_dgrad() if (c3ok and _conv3_use_hip("dgrad", (N, Hi, Wi, p), hip_dgrad, miopen_dgrad)) \
-                else miopen_dgrad()
-        else:
-            da1_4, dw2, _ = torch.ops.aten.convolution_backward(dz2_4, a1_4, w2, None, [s, s], [1, 1], [1, 1], False,
-                                                                [0, 0], 1, [True, bool(need[5]), False])
+        da1_4 = hip_dgrad() if (c3ok and _conv3_use_hip("dgrad", (N, Hi, Wi, p), hip_dgrad, miopen_dgrad)) \
+            else miopen_dgrad()
         if not da1_4.is_contiguous(memory_format=torch.channels_last):
             da1_4 = da1_4.contiguous(memory_format=torch.channels_last)
         da1 = _as2d(da1_4)

@@ -969,8 +969,9 @@ def test_reference_loop_body_with_stock_adam(dev):
     criterion = torch.nn.CrossEntropyLoss().to(dev)
 
     def reference_loop(side):
-        saved = SC.SIDE_WGRAD
+        saved, saved3 = SC.SIDE_WGRAD, SC.CONV3
         SC.SIDE_WGRAD = side
+        SC.CONV3 = "hip"          # stride-1 3x3 forward / d-input on this repository's (deterministic) kernel
         try:
             enc, dec = copy.deepcopy(enc0).train(), copy.deepcopy(dec0).train()
             dec_opt = torch.optim.Adam(params=filter(lambda p: p.requires_grad, dec.parameters()), lr=4e-4)
@@ -998,7 +999,7 @@ def test_reference_loop_body_with_stock_adam(dev):
             params = {k: p.detach().clone() for k, p in list(dec.named_parameters()) + list(enc.named_parameters())}
             return first, params, loss.detach()
         finally:
-            SC.SIDE_WGRAD = saved
+            SC.SIDE_WGRAD, SC.CONV3 = saved, saved3
 
     g_side, p_side, loss_side = reference_loop(True)
     g_main, p_main, loss_main = reference_loop(False)
@@ -1014,8 +1015,18 @@ def test_reference_loop_body_with_stock_adam(dev):
         assert e <= 1e-4, "gradient of %s differs between side-stream and main-stream runs: %.3e" % (k, e)
         noise = rel_err(g_again[k], g_main[k]) if float(g_main[k].abs().max()) > 0 else 0.0
         worst_noise = max(worst_noise, noise)
-    # ... and it is the library's noise, not the second stream's: two main-stream-only runs differ just as much
-    assert worst_g <= 10 * worst_noise + 1e-6, (worst_g, worst_noise)
+    # Which tensors may differ at all?  Library kernels that sum with atomics give a different last bit whenever the
+    # order in which their workgroups run changes, and a second stream changes it: MIOpen's 3x3 weight gradients
+    # (conv2.weight), and its strided 3x3 d-input in layer4.0 / layer3.0 / layer2.0 -- everything upstream of those in
+    # the backward sweep inherits the noise.  What this repository's kernels alone produce must be bit-identical
+    # whichever stream ran it: the whole decoder and the last two blocks of layer4 (backward reaches them first).
+    differing = sorted(k for k in g_main if not torch.equal(g_side[k], g_main[k]))
+    dec_keys = set(dict(dec0.named_parameters()))
+    strict = [k for k in g_main if k in dec_keys or
+              (k.startswith(("resnet.7.1.", "resnet.7.2.")) and not k.endswith("conv2.weight"))]
+    assert len(strict) > 30
+    bad = [k for k in strict if k in differing]
+    assert not bad, "differs between side-stream and main-stream runs although no library kernel is upstream: %s" % bad[:6]
     for k in p_main:      # Adam normalises its step: elements whose gradient is at noise level move by +-lr in either run
         err = (p_side[k] - p_main[k]).abs().max().item()
         assert err <= 2 * 2 * 4e-4 * 1.01, "parameter %s differs after two steps: %.3e" % (k, err)
@@ -1044,6 +1055,7 @@ def test_reference_loop_body_with_stock_adam(dev):
         lr = 4e-4 if any(k == kd for kd, _ in dec_b.named_parameters()) else 1e-4
         assert err <= 2 * 2 * lr * 1.01, "%s: abs err %.3e after two steps" % (k, err)
     _report(["side-stream vs main-stream runs of the reference loop body: %d gradient tensors, worst rel err %.3e "
-             "(two main-stream-only runs: %.3e)" % (len(g_main), worst_g, worst_noise), "reference loop body vs harness path: second-step loss rel err %.3e, max abs parameter "
+             "(two main-stream-only runs: %.3e); %d tensors differ at all, none of the %d that have no library (atomic) "
+             "kernel upstream" % (len(g_main), worst_g, worst_noise, len(differing), len(strict)), "reference loop body vs harness path: second-step loss rel err %.3e, max abs parameter "
              "difference %.3e" % (rel_err(loss_b, loss_side), worst)],
             "reference loop body with stock torch.optim.Adam")
