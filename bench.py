@@ -40,6 +40,7 @@ for _p in (os.path.join(ROOT, "indonesian-image-captioning_amd"), ROOT):
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+LAUNCH_FLOOR_US = 1.87     # see roofline.launch_floor
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -451,6 +452,7 @@ def main():
             if dbf:            # every operand the step streams is stored as bf16 in this mode
                 eb //= 2
             ach_e = eb / (step_us * 1e-6) / 1e9
+            nlaunch = 6 if (args.attn_handoff and pooled) else 7
             ctx_bytes = (2 if dbf else 4) * args.batch * (64 if pooled else 196) * 2048
             if args.attn_handoff and pooled:      # the one-launch form also reads att1 (the scores live in it)
                 ctx_bytes += 4 * args.batch * 196 * cfg["attention_dim"]
@@ -466,6 +468,14 @@ def main():
                                           if (args.attn_handoff and pooled) else
                                           "decode step fwd = skinny_kernel x3 + attn_scores + attn_context + scn_mix_fwd + "
                                           "lstm_fwd: 7 launches") + " (the fused SCN-cell+attention step of north_star)",
+                               # measured floor of a dependent launch on this chip (tools/chain_floor.hip, hipGraph replay
+                               # of trivial 256-workgroup kernels: profiles/r02_decode_step_launch_floor.txt): what the
+                               # step's launch boundaries cost before any byte of its operands moves
+                               "launch_floor": {"us_per_dependent_launch": LAUNCH_FLOOR_US, "launches": nlaunch,
+                                                "floor_us": round(nlaunch * LAUNCH_FLOOR_US, 1),
+                                                "achieved_GBs_in_the_remaining_time":
+                                                    round(eb / max(step_us - nlaunch * LAUNCH_FLOOR_US, 1e-3) / 1e3, 1),
+                                                "source": "profiles/r02_decode_step_launch_floor.txt"},
                                "algorithmic_bytes_per_step": ab, "avg_step_us": round(step_us, 2),
                                "executed_bytes_per_step": eb,
                                "attention_path": "pooled: context / d alpha over the trunk's 8x8 map (scnattn_pool), "
