@@ -262,7 +262,7 @@ def main():
 
     from scnattn import _lib
     from scnattn import functional as SF
-    from trains.harness import TrainStep, synthetic_batch, DEFAULTS
+    from trains.harness import TrainStep, synthetic_batch
     if args.no_fused_conv:
         from scnattn import conv as _conv
         _conv.ENABLED = False

@@ -15,7 +15,6 @@ What they close ("parity gaps"):
 """
 import copy
 
-import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F

@@ -1,12 +1,11 @@
 """A few launches of csrc/cgemm.hip on chosen shapes, for rocprofv3 --pmc passes (see tools/README.md)."""
-import ctypes as C
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "indonesian-image-captioning_amd")); sys.path.insert(0, ROOT)
 import torch
-from scnattn._lib import call, ptr, stream_of, ConvExtra
+from scnattn._lib import call, ptr, stream_of
 
 dev = torch.device("cuda:0")
 WS = torch.empty(16 << 20, device=dev)
