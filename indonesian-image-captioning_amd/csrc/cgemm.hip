@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int tm = bid / g.nt, tn = bid - tm * g.nt;
-    const int m0 = tm * TM, n0 = tn * TN;
+    const int m0 = tm * TM, n0 = tn * (W41 ? 64 : TN);      // 4 x 1 layout: 64-column tiles
     const int zb = blockIdx.y / g.S, sp = blockIdx.y - zb * g.S;
     const float* A = g.A + (long)zb * g.sA;
     const float* B = g.B + (long)zb * g.sB;
@@ -207,11 +207,11 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
         if (!B_MC) {
             const int row = chunk * 16 + (lane >> 2), gsrc = (lane & 3) ^ ((row >> 2) & 3);
             const int grow = n0 + row;
-            b_ok[c] = grow < g.N;
+            b_ok[c] = grow < g.N && (!W41 || row < 64);
             b_off[c] = (unsigned)(((long)grow * g.ldb + gsrc * 4) * 4);
         } else {
             const int col = n0 + 4 * (lane & 31);
-            b_ok[c] = col < g.N;
+            b_ok[c] = col < g.N && (!W41 || (lane & 31) < 16);
             b_off[c] = (unsigned)(((long)(chunk * 2 + (lane >> 5)) * g.ldb + col) * 4);
         }
     }
@@ -825,13 +825,13 @@ int cgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
                      ((long)(M - 1) * ldc + N) * 4 < 0x7fffffffL && (long)M * N * 4 < 0x7fffffffL;
     SCN_ARG(epi == 0 || vec, "cgemm: the statistics epilogues need N % 4 == 0, ldc % 4 == 0 and a 16-byte aligned C");
     // row tile: 64 rows when the 128-row grid alone cannot give every CU a workgroup but the 64-row grid can come closer
-    const int nt = cdiv(N, TN);
     int mi = 2;
-    if ((long)cdiv(M, 128) * nt * batch < 256 && M > 64 && c3 != 1 && c3 != 2) mi = 1;
+    if ((long)cdiv(M, 128) * cdiv(N, TN) * batch < 256 && M > 64 && c3 != 1 && c3 != 2) mi = 1;
     if (N <= 64 && M >= 128 && g_cgemm_w41 && c3 != 3) mi = 4;     // 128 x 64 tiles, waves 4 x 1 (layer1's 64-channel maps)
     if (g_cgemm_mi == 1 || g_cgemm_mi == 2) mi = g_cgemm_mi;
     if (ex && ex->force_mi > 0) mi = ex->force_mi;
-    SCN_ARG(mi == 1 || mi == 2 || (mi == 4 && N <= 64 && c3 != 3), "cgemm: bad tile selector (4 needs N <= 64)");
+    SCN_ARG(mi == 1 || mi == 2 || (mi == 4 && c3 != 3), "cgemm: bad tile selector");
+    const int nt = cdiv(N, mi == 4 ? 64 : TN);
     const int tmrows = mi == 4 ? 128 : 64 * mi, mt = cdiv(M, tmrows);
     const long tiles = (long)mt * nt * batch;
     int S = 1;

@@ -110,6 +110,22 @@ def check():
     dy = torch.randn(R, Cout, generator=g).to(dev)
     dw = cgemm(dy, xm.view(-1, Cin), True, False, torch.empty(Cout, Cin, device=dev), Cout, Cin, R, ex)
     e = rel(dw, dy.double().t() @ xs.double()); assert e < 1e-5, ("gather wgrad", e)
+    # the 4 x 1 wave layout (128 x 64 tiles) forced on wider outputs: forward with both fusions, dgrad, split-K
+    for (R, Cin, Cout) in [(1000, 128, 256), (4096, 256, 192)]:
+        x = torch.randn(R, Cin, generator=g).to(dev); w = (torch.randn(Cout, Cin, generator=g) * 0.1).to(dev)
+        dy = torch.randn(R, Cout, generator=g).to(dev)
+        sc = (1 + 0.5 * torch.randn(Cin, generator=g)).to(dev); sh = (0.2 * torch.randn(Cin, generator=g)).to(dev)
+        ss = torch.stack([sc, sh], dim=1).contiguous()
+        for split in (0, 2):
+            part = torch.full((lib().scnattn_cgemm_row_tiles(R), 2, Cout), float("nan"), device=dev)
+            ex = ConvExtra(pro=1, epi=1, pro_ss=ss.data_ptr(), stat_partial=part.data_ptr(), force_mi=4, force_split=split)
+            y = cgemm(x, w, False, True, torch.empty(R, Cout, device=dev), R, Cout, Cin, ex)
+            y_ref = torch.relu(x.double() * sc.double() + sh.double()) @ w.double().t()
+            e = rel(y, y_ref); assert e < 3e-6, ("w41 fwd", R, Cin, Cout, split, e)
+            e1 = rel(part[:, 0].double().sum(0), y_ref.sum(0)); e2 = rel(part[:, 1].double().sum(0), (y_ref * y_ref).sum(0))
+            assert e1 < 2e-5 and e2 < 2e-5, ("w41 stats", R, Cin, Cout, split, e1, e2)
+            dx = cgemm(dy, w, False, False, torch.empty(R, Cin, device=dev), R, Cin, Cout, ConvExtra(force_mi=4, force_split=split))
+            e = rel(dx, dy.double() @ w.double()); assert e < 3e-6, ("w41 dgrad", R, Cin, Cout, split, e)
     # TT and odd shapes through the generic entry
     a = torch.randn(96, 200, generator=g).to(dev); b = torch.randn(60, 96, generator=g).to(dev)
     o = cgemm(a, b, True, True, torch.empty(200, 60, device=dev), 200, 60, 96)
@@ -287,7 +303,7 @@ def stagger():
 
 def sweep3():
     """3x3 forward (with the statistics epilogue, as the block issues it) and dgrad: row tile x split-K factor."""
-    combos = [(2, 4), (2, 3), (2, 2), (2, 1), (1, 4), (1, 3), (1, 2), (1, 1)]
+    combos = [(2, 4), (2, 2), (1, 2), (1, 1), (4, 1), (4, 2), (4, 3), (4, 4)]
     print("3x3 (mi,S): " + " ".join("%9s" % (c,) for c in combos) + " | policy")
     for name, H, Cin in [("l2", 32, 128), ("l3", 16, 256), ("l4", 8, 512)]:
         N, Cout = 32, Cin
