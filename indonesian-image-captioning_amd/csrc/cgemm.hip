@@ -836,7 +836,10 @@ int cgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
     const long tiles = (long)mt * nt * batch;
     int S = 1;
     if (ws && tiles < 224 && K >= 2 * g_cgemm_kmin) {
-        S = (int)((g_cgemm_target + tiles - 1) / tiles);
+        // 3x3 weight gradient: its gathered operand makes the k-loop latency-bound, a third resident workgroup per CU
+        // pays (measured 115-120 us at ~768 workgroups against 127-142 at ~512; the 1x1 weight gradients are best at 512)
+        const long target = (c3 == 3 && g_cgemm_target == 512) ? 768 : g_cgemm_target;
+        S = (int)((target + tiles - 1) / tiles);
         const int smax = K / g_cgemm_kmin;
         if (S > smax) S = smax;
         if (S > CG_MAX_SPLIT) S = CG_MAX_SPLIT;

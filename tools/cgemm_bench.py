@@ -324,8 +324,43 @@ def sweep3():
             print("%-3s %-9s " % (name, kind) + " ".join("%9.1f" % t for t in ts[:-1]) + " | %6.1f" % ts[-1], flush=True)
 
 
+def sweepw():
+    """3x3 weight gradient: row tile x split-K target (workgroups aimed for), against MIOpen."""
+    combos = [(2, tgt) for tgt in (512, 768, 1024, 1536, 2048, 3072, 4096)]
+    print("3x3 wgrad (mi,target): " + " ".join("%10s" % (c,) for c in combos) + " |   miopen")
+    for name, H, Cin in [("l2", 32, 128), ("l3", 16, 256), ("l4", 8, 512)]:
+        N, Cout = 32, Cin
+        x = torch.randn(N, Cin, H, H, device=dev).contiguous(memory_format=torch.channels_last)
+        w = (0.1 * torch.randn(Cout, Cin, 3, 3, device=dev)).contiguous(memory_format=torch.channels_last)
+        dy = torch.randn(N, Cout, H, H, device=dev).contiguous(memory_format=torch.channels_last)
+        dw = torch.empty_like(w)
+        ts = []
+        for mi, tgt in combos:
+            SF.set_option("cgemm_mi", mi); SF.set_option("cgemm_target", tgt)
+            ts.append(t_us(lambda: call("scnattn_conv3x3_wgrad", stream_of(x), N, H, H, Cin, Cout, 1, ptr(dy), ptr(x), ptr(dw), ptr(WS), WS.numel())))
+        SF.set_option("cgemm_mi", 0); SF.set_option("cgemm_target", 512)
+        m = t_us(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False]))
+        print("%-3s " % name + " " * 19 + " ".join("%10.1f" % t for t in ts) + " | %8.1f" % m, flush=True)
+    print("1x1 wgrad (same targets), plain / with the BatchNorm prologue on the activation operand")
+    for name, R, Cin, Cout in [("l1.conv3", 131072, 64, 256), ("l2.conv1", 32768, 512, 128), ("l2.conv3", 32768, 128, 512),
+                               ("l3.conv1", 8192, 1024, 256), ("l3.conv3", 8192, 256, 1024), ("l4.conv1", 2048, 2048, 512),
+                               ("l4.conv3", 2048, 512, 2048)]:
+        x = torch.randn(R, Cin, device=dev); dy = torch.randn(R, Cout, device=dev); dw = torch.empty(Cout, Cin, device=dev)
+        ss = torch.rand(Cin, 2, device=dev)
+        ex_w = ConvExtra(pro=2, pro_ss=ss.data_ptr())
+        ts, tp = [], []
+        for mi, tgt in combos:
+            SF.set_option("cgemm_target", tgt)
+            ts.append(t_us(lambda: cgemm(dy, x, True, False, dw, Cout, Cin, R)))
+            tp.append(t_us(lambda: cgemm(dy, x, True, False, dw, Cout, Cin, R, ex_w)))
+        SF.set_option("cgemm_target", 512)
+        print("%-9s " % name + " ".join("%6.1f/%-6.1f" % (a, b) for a, b in zip(ts, tp)), flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what == "sweepw":
+        sweepw()
     if what == "sweep3":
         sweep3()
     if what == "stagger":
