@@ -439,7 +439,8 @@ def main():
             traffic, tsrc = None, None
             pooled = not args.dense_attention
             dbf = args.decoder_dtype == "bf16"
-            pmc_name = ("r02_pmc_decode_step_fwd_%s_bf16.json" if dbf else "r01_pmc_decode_step_fwd_%s.json") \
+            pmc_name = ("r02_pmc_decode_step_fwd_%s_bf16.json" if dbf else
+                        "r02_pmc_decode_step_fwd_%s.json" if pooled else "r01_pmc_decode_step_fwd_%s.json") \
                 % ("pooled" if pooled else "dense")
             pmc = os.path.join(ROOT, "profiles", pmc_name)
             if args.batch == 32 and os.path.exists(pmc):   # PMC passes cannot run inside this process;
