@@ -837,12 +837,28 @@ int cgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
     int S = 1;
     if (ws && tiles < 224 && K >= 2 * g_cgemm_kmin) {
         // 3x3 weight gradient: its gathered operand makes the k-loop latency-bound, a third resident workgroup per CU
-        // pays (measured 115-120 us at ~768 workgroups against 127-142 at ~512; the 1x1 weight gradients are best at 512)
-        const long target = (c3 == 3 && g_cgemm_target == 512) ? 768 : g_cgemm_target;
+        // pays (measured 115-120 us at ~768 workgroups against 127-142 at ~512; the 1x1 weight gradients are best at 512).
+        // Very deep non-transposed products (the decoder's d hidden = d preds . fc.weight, K = vocabulary): ~1100
+        // workgroups (1632 x 512 x 10000: 208 -> 158 us, tools/cgemm_bench.py gemmsweep).
+        long target = g_cgemm_target;
+        if (g_cgemm_target == 512) {
+            if (c3 == 3) target = 768;
+            else if (!tA && K >= 4096 && !c3) target = 1100;
+        }
         S = (int)((target + tiles - 1) / tiles);
         const int smax = K / g_cgemm_kmin;
         if (S > smax) S = smax;
         if (S > CG_MAX_SPLIT) S = CG_MAX_SPLIT;
+        while (S > 1 && (long)S * batch * M * N > ws_floats) --S;
+        if (S < 1) S = 1;
+    }
+    // A grid of one to three residency rounds (224 .. 767 tiles of a deep product) ends in a long tail: the last round
+    // runs with most CUs idle.  Splitting K to ~1200 workgroups evens it out (10000 x 512 x 1632: 208 -> 154 us,
+    // 6272 x 512 x 2048: 143 -> 128 us).  K >= 1024 keeps every convolution of the trunk on its measured setting.
+    if (ws && !c3 && S == 1 && tiles >= 224 && tiles < 768 && K >= 1024 && g_cgemm_target == 512) {
+        S = (int)((1200 + tiles / 2) / tiles);
+        const int smax = K / (2 * g_cgemm_kmin);
+        if (S > smax) S = smax;
         while (S > 1 && (long)S * batch * M * N > ws_floats) --S;
         if (S < 1) S = 1;
     }

@@ -96,7 +96,7 @@ struct Saved {
     float *att1h, *ench;      // bf16 copies (raw 16-bit elements) of att1 and of the encoder map, bf16 mode only
 };
 
-constexpr long GEMM_WS_FLOATS = 8L << 20;   // 32 MiB of split-K partials for the big GEMMs
+constexpr long GEMM_WS_FLOATS = 24L << 20;  // 96 MiB of split-K partials for the big GEMMs (d fc.weight: 4 slabs of 10000 x 512)
 
 struct FwdScratch {
     float *WcatA, *WD, *slabA, *e, *slabC, *xcat, *slabD, *gws, *y, *cnt;

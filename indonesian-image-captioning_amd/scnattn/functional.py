@@ -54,7 +54,7 @@ def _gemm_workspace(dev):
            threading.get_ident())
     ws = _gemm_ws.get(key)
     if ws is None:
-        ws = _gemm_ws[key] = torch.empty(8 << 20, device=dev, dtype=torch.float32)
+        ws = _gemm_ws[key] = torch.empty(24 << 20, device=dev, dtype=torch.float32)
     return ws
 
 

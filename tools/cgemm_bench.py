@@ -357,10 +357,43 @@ def sweepw():
         print("%-9s " % name + " ".join("%6.1f/%-6.1f" % (a, b) for a, b in zip(ts, tp)), flush=True)
 
 
+def gemmsweep():
+    """The decoder's dense products (BASELINE dims): row tile x split-K factor against the policy's own pick."""
+    shapes = [("att1 y", 2048, 512, 2048, False, True), ("att1 dense", 6272, 512, 2048, False, True),
+              ("fc", 1632, 10000, 512, False, True), ("dHd", 1632, 512, 10000, False, False),
+              ("dWfc", 10000, 512, 1632, True, False), ("dWe", 512, 2048, 6272, True, False),
+              ("denc", 6272, 2048, 512, False, False), ("dWa", 2048, 2048, 1632, True, False),
+              ("ex", 1632, 2048, 512, False, False), ("dWaM", 512, 2048, 1632, True, False),
+              ("dWbeta", 2048, 512, 1632, True, False), ("dWd", 512, 512, 1632, True, False),
+              ("demb", 1632, 512, 2048, False, True), ("dWc_g", 512, 512, 1632, True, False)]
+    combos = [(mi, S) for mi in (2, 1) for S in (1, 2, 3, 4, 6, 8, 12, 16)]
+    print("%-11s %-18s | policy us (TF) | best (mi,S) us (TF) | all: %s" % ("name", "MxNxK", " ".join("%d/%d" % c for c in combos)))
+    for name, M, N, K, ta, tb in shapes:
+        a = torch.randn(K, M, device=dev) if ta else torch.randn(M, K, device=dev)
+        b = torch.randn(N, K, device=dev) if tb else torch.randn(K, N, device=dev)
+        out = torch.empty(M, N, device=dev)
+        fl = 2.0 * M * N * K
+        t0 = t_us(lambda: cgemm(a, b, ta, tb, out, M, N, K))
+        ts = []
+        for mi, S in combos:
+            if S > 1 and K // S < 128:
+                ts.append(float("nan")); continue
+            ex = ConvExtra(force_mi=mi, force_split=S)
+            try:
+                ts.append(t_us(lambda: cgemm(a, b, ta, tb, out, M, N, K, ex)))
+            except Exception:
+                ts.append(float("nan"))
+        best = min((t, c) for t, c in zip(ts, combos) if t == t)
+        print("%-11s %-18s | %6.1f (%5.1f) | %s %6.1f (%5.1f) | %s" % (name, "%dx%dx%d" % (M, N, K), t0, fl / t0 / 1e6, best[1], best[0], fl / best[0] / 1e6,
+                                                                      " ".join("%.0f" % t for t in ts)), flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what == "sweepw":
         sweepw()
+    if what == "gemmsweep":
+        globals()["gemmsweep"]()
     if what == "sweep3":
         sweep3()
     if what == "stagger":
