@@ -854,8 +854,9 @@ int cgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
     }
     // A grid of one to three residency rounds (224 .. 767 tiles of a deep product) ends in a long tail: the last round
     // runs with most CUs idle.  Splitting K to ~1200 workgroups evens it out (10000 x 512 x 1632: 208 -> 154 us,
-    // 6272 x 512 x 2048: 143 -> 128 us).  K >= 1024 keeps every convolution of the trunk on its measured setting.
-    if (ws && !c3 && S == 1 && tiles >= 224 && tiles < 768 && K >= 1024 && g_cgemm_target == 512) {
+    // 6272 x 512 x 2048: 143 -> 128 us).  K >= 1536 keeps the trunk's forward / d-input convolutions on their measured
+    // setting (layer3's 8192 x 256 x 1024 loses 3-5 us to such a split: its statistics epilogue moves into the reduce pass).
+    if (ws && !c3 && S == 1 && tiles >= 224 && tiles < 768 && K >= 1536 && g_cgemm_target == 512) {
         S = (int)((1200 + tiles / 2) / tiles);
         const int smax = K / (2 * g_cgemm_kmin);
         if (S > smax) S = smax;
