@@ -37,7 +37,11 @@ const char* scnattn_last_error(void);
  * workgroups share the scores of a batch row through an in-launch hand-off; default 0 = two launches: measured equal),
  * "handoff_check" (1: scnattn_seq_fwd synchronises at its end and returns an error if a hand-off wait timed out),
  * "decoder_bf16" (1: the sequence drivers stream bf16 copies of the recurrent weights, att1 and the encoder map --
- * see scnattn_skinny_gemm_bf16w; needs D, F, E, A multiples of 4, otherwise the fp32 path runs).
+ * see scnattn_skinny_gemm_bf16w; needs D, F, E, A multiples of 4, otherwise the fp32 path runs),
+ * tuning of the dense / convolution GEMM (csrc/cgemm.hip): "use_cgemm" (0: every product on the round-1 sgemm kernel),
+ * "cgemm_mi" (0 auto; 1 / 2 force the 64- / 128-row tile), "cgemm_target" (workgroups a split-K product aims for, 512),
+ * "cgemm_kmin" (smallest K per slab, 128), "cgemm_vec" (0: scalar epilogue), "cgemm_w41" (0: never the 128 x 64 tile
+ * with the 4 x 1 wave layout), "cgemm_stagger" (start delay per residency round in units of 64 cycles; experiment).
  * Returns -1 for an unknown name or value. */
 int scnattn_set_option(const char* name, int value);
 /* Sums since the last call: out6 = {forward loop ms, forward steps, backward loop ms, backward steps,
