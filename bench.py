@@ -203,6 +203,8 @@ def main():
     ap.add_argument("--dtype", default=None, choices=["f32", "bf16"],
                     help="shorthand: bf16 = --encoder-dtype bf16 --decoder-dtype bf16 (BASELINE configs[4] flavour, a "
                          "second line next to the fp32 headline)")
+    ap.add_argument("--lib-option", action="append", default=[], metavar="NAME=INT",
+                    help="A/B: scnattn_set_option(NAME, INT) before the step is built (include/scnattn.h lists the names)")
     ap.add_argument("--force-dist", action="store_true",
                     help="diagnostics: run the multi-rank code path (RCCL group, barriers, reducers) with one rank")
     ap.add_argument("--forward-only", action="store_true", help="diagnostics: decoder forward only (PMC passes)")
@@ -271,6 +273,9 @@ def main():
     if args.no_side_wgrad:
         from scnattn import conv as _conv2
         _conv2.SIDE_WGRAD = False
+    for kv in args.lib_option:
+        name, _, val = kv.partition("=")
+        SF.set_option(name, int(val))
     SF.set_option("attn_handoff", args.attn_handoff)
     if args.ksplit:
         SF.set_option("ksplit", args.ksplit)

@@ -212,12 +212,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(long n4, int C, const T* 
 // MASKZ: the ReLU mask is recomputed from z with the forward's own expression, fma((z-mean)*invstd, gamma, beta) > 0,
 // instead of being read back from y -- valid when no residual was added before the ReLU (bn1/bn2 of a bottleneck);
 // the backward pass then never touches y (one 4-byte read per element less in each of its two passes).
-template <typename T, bool RELU, bool MASKZ>
+// GOUT: the masked gradient g is also WRITTEN (it is the gradient of the residual branch, an output of the backward pass
+// anyway): the element-wise second pass then reads g and z only -- not dy and y again -- and writes dz only: 7 map
+// transfers per BatchNorm(+residual)+ReLU backward instead of 8.
+template <typename T, bool RELU, bool MASKZ, bool GOUT = false>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(int R, int C, int rows_per_chunk, const T* __restrict__ dy,
                                                             const T* __restrict__ y, const T* __restrict__ z,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            float* __restrict__ partial) {
+                                                            float* __restrict__ partial, T* __restrict__ gout = nullptr) {
     __shared__ float red[16][2][64 + 1];
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.x * 64 + cl * 4;
@@ -244,7 +247,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(int R, int C, int ro
                 if (RELU && !MASKZ) yy[j] = IO<T>::ld(y + off);
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j) {
+                f32x4 gm;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     float gv = g[j][k];
@@ -254,9 +258,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(int R, int C, int ro
                         if (!on) gv = 0.f;
                     }
                     if (!ok[j]) gv = 0.f;
+                    gm[k] = gv;
                     sg[k] += gv;
                     sx[k] = fmaf(gv, xh, sx[k]);
                 }
+                if (GOUT && ok[j]) IO<T>::st(gout + (long)(r + 16 * j) * C + c, gm);
+            }
         }
     }
 #pragma unroll
@@ -336,6 +343,10 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(long n4, int R, int C, c
         if (dres) IO<T>::st(dres + i * 4, g);
     }
 }
+
+}  // namespace
+int g_bn_gfirst = 1;      // 1: see bn_bwd_t (option "bn_gfirst", A/B)
+namespace {
 
 inline int pick_chunks(int R, int C, int* rows_per_chunk) {
     const int colgroups = cdiv(C, 64);
@@ -444,7 +455,11 @@ static int bn_bwd_t(hipStream_t st, int R, int C, const T* dy, const T* y, const
     const int nchunk = pick_chunks(R, C, &rpc);
     dim3 rgrid(cdiv(C, 64), nchunk), block(256);
     const bool maskz = relu && !y;       // ReLU mask recomputed from z (no residual in front of the ReLU)
+    // fp32 maps with a residual branch: the reduction pass writes g = dy * [y > 0] as d residual, the second pass reads it
+    // (bf16 maps keep the old form: their dz is computed from the unrounded g)
+    const bool gfirst = relu && !maskz && dres && dz && sizeof(T) == 4 && g_bn_gfirst;
     if (maskz)     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true, true>), rgrid, block, 0, st, R, C, rpc, dy, y, z, mean, invstd, gamma, beta, partial);
+    else if (relu && gfirst) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true, false, true>), rgrid, block, 0, st, R, C, rpc, dy, y, z, mean, invstd, gamma, beta, partial, dres);
     else if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true, false>), rgrid, block, 0, st, R, C, rpc, dy, y, z, mean, invstd, gamma, beta, partial);
     else           hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false, false>), rgrid, block, 0, st, R, C, rpc, dy, y, z, mean, invstd, gamma, beta, partial);
     SCN_LAUNCH_CHECK();
@@ -456,7 +471,12 @@ static int bn_bwd_t(hipStream_t st, int R, int C, const T* dy, const T* y, const
 #define SCN_BN_DX(RELU_, TRAIN_, MASKZ_)                                                                                  \
     hipLaunchKernelGGL((bn_bwd_dx_kernel<T, RELU_, TRAIN_, MASKZ_>), grid, block, 0, st, n4, R, C, dy, y, z, mean, invstd, \
                        gamma, beta, dbeta, dgamma, dz, dres)
-        if (maskz && train) SCN_BN_DX(true, true, true);
+        if (gfirst) {
+            if (train) hipLaunchKernelGGL((bn_bwd_dx_kernel<T, false, true, false>), grid, block, 0, st, n4, R, C, dres, y, z, mean,
+                                          invstd, gamma, beta, dbeta, dgamma, dz, (T*)nullptr);
+            else       hipLaunchKernelGGL((bn_bwd_dx_kernel<T, false, false, false>), grid, block, 0, st, n4, R, C, dres, y, z, mean,
+                                          invstd, gamma, beta, dbeta, dgamma, dz, (T*)nullptr);
+        } else if (maskz && train) SCN_BN_DX(true, true, true);
         else if (maskz) SCN_BN_DX(true, false, true);
         else if (relu && train) SCN_BN_DX(true, true, false);
         else if (relu) SCN_BN_DX(true, false, false);
