@@ -203,6 +203,9 @@ def main():
     ap.add_argument("--dtype", default=None, choices=["f32", "bf16"],
                     help="shorthand: bf16 = --encoder-dtype bf16 --decoder-dtype bf16 (BASELINE configs[4] flavour, a "
                          "second line next to the fp32 headline)")
+    ap.add_argument("--no-tagger-overlap", action="store_true",
+                    help="A/B (--with-tagger): the tagger's forward pass in line on the main stream instead of beside the "
+                         "caption encoder's on the side stream")
     ap.add_argument("--lib-option", action="append", default=[], metavar="NAME=INT",
                     help="A/B: scnattn_set_option(NAME, INT) before the step is built (include/scnattn.h lists the names)")
     ap.add_argument("--force-dist", action="store_true",
@@ -300,6 +303,7 @@ def main():
     ts = TrainStep(kind=args.workload, fine_tune_encoder=fine_tune, device=dev, encoder=not args.decoder_only,
                    batch_size=args.batch, max_len=args.max_len, graph_encoder=args.graph, tagger=args.with_tagger, force_reduce=args.force_dist,
                    encoder_dtype=args.encoder_dtype, decoder_dtype=args.decoder_dtype,
+                   tagger_overlap=not args.no_tagger_overlap,
                    pooled_attention=not args.dense_attention, bucket_mb=args.bucket_mb)
     cfg = ts.cfg
     imgs, tags, caps, caplens = synthetic_batch(args.batch, cfg["vocab_size"], cfg["max_len"], cfg["image_size"],

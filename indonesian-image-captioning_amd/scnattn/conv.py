@@ -41,10 +41,12 @@ _bufs = {}
 
 
 def _buffers(dev):
-    """Per-device scratch, reused in stream order: split-K slabs of the GEMMs and the statistics partials."""
-    b = _bufs.get(dev)
+    """Scratch per (device, current stream), reused in stream order: split-K slabs of the GEMMs and the statistics
+    partials.  Per stream because two trunks may run at once (the frozen tagger beside the caption encoder)."""
+    key = (dev, torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device()))
+    b = _bufs.get(key)
     if b is None:
-        b = _bufs[dev] = (torch.empty(16 << 20, device=dev, dtype=torch.float32),     # 64 MiB split-K slabs
+        b = _bufs[key] = (torch.empty(16 << 20, device=dev, dtype=torch.float32),     # 64 MiB split-K slabs
                           torch.empty(2 << 20, device=dev, dtype=torch.float32),      # [64-row blocks][2][C] partials
                           torch.empty(2 << 20, device=dev, dtype=torch.float32))      # BN chunk partials (bn_stats)
     return b

@@ -509,11 +509,14 @@ _bn_fn = None
 
 
 def _bn_workspace(dev, C):
-    ws = _bn_ws.get(dev)
+    # stream-ordered reuse: one buffer per (device, stream) -- two trunks may run on two streams at once (the frozen
+    # tagger beside the caption encoder, trains/harness.py)
+    key = (dev, torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device()))
+    ws = _bn_ws.get(key)
     if ws is None or ws.numel() < 512 * C:
         need = max(_lib.lib().scnattn_bn_workspace_floats(C), 1 << 20)
         ws = torch.empty(need, device=dev, dtype=torch.float32)
-        _bn_ws[dev] = ws    # stream-ordered reuse: every BN call on the device runs on the current stream
+        _bn_ws[key] = ws
     return ws
 
 

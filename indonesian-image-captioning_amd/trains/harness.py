@@ -60,7 +60,7 @@ def build_decoder(kind, cfg):
 class TrainStep:
     def __init__(self, kind="attention_scn", fine_tune_encoder=True, device="cuda", seed=1234, encoder=True,
                  bucket_mb=32, graph_encoder=False, tagger=False, force_reduce=False, encoder_dtype="f32",
-                 decoder_dtype="f32",
+                 decoder_dtype="f32", tagger_overlap=True,
                  fused_loss=True, pooled_attention=True, **overrides):
         self.cfg = dict(DEFAULTS)
         self.cfg.update(overrides)
@@ -74,6 +74,7 @@ class TrainStep:
         # decoder "bf16": the operands the recurrence streams every step (recurrent weights, att1, the trunk map) are
         # read as bf16 copies made once per call (include/scnattn.h, option "decoder_bf16"); fp32 accumulate, fp32
         # softmax / LSTM state / master weights / gradients.  A process-wide option of the library.
+        self.tagger_overlap = tagger_overlap
         self.decoder_bf16 = decoder_dtype == "bf16"
         if torch.device(device).type == "cuda":
             SF.set_option("decoder_bf16", 1 if self.decoder_bf16 else 0)
@@ -143,6 +144,20 @@ class TrainStep:
         `encoder_out = encoder(imgs)` materialises the (B,14,14,2048) map, `decoder(encoder_out, ...)` receives only
         that tensor (and finds the trunk map EncoderCaption attached to it).  The default hands the trunk map over
         explicitly and skips the pooling kernel and its 51 MB write."""
+        tag_event = None
+        if self.tagger is not None and self.tagger_overlap and imgs.is_cuda and self.encoder is not None:
+            # The frozen tagger's forward pass shares nothing with the caption encoder's: it runs on the side stream
+            # (scnattn/conv.py: a stream probed to be concurrent with this one) beside it; the decoder is the first
+            # consumer of the tags and waits for them by event.
+            from scnattn import conv as _conv
+            main = torch.cuda.current_stream(imgs.device)
+            side = _conv._side(imgs.device)
+            side.fork(main, imgs)
+            with torch.cuda.stream(side.stream), torch.no_grad(), \
+                    torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.encoder_bf16):
+                tags = self.tagger(imgs).float()
+            tag_event = torch.cuda.Event()
+            tag_event.record(side.stream)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.encoder_bf16):
             if self.encoder is not None:
                 if self.pooled_attention and not self.graphed and not drop_in:
@@ -150,10 +165,13 @@ class TrainStep:
                     encoder_out = None
                 else:
                     encoder_out = self.encoder_call(imgs)
-            if self.tagger is not None:
+            if self.tagger is not None and tag_event is None:
                 tags = self.tagger(imgs)
-        if self.tagger is not None:
+        if self.tagger is not None and tag_event is None:
             tags = tags.float()
+        if tag_event is not None:
+            torch.cuda.current_stream(imgs.device).wait_event(tag_event)
+            tags.record_stream(torch.cuda.current_stream(imgs.device))
         if self.kind == "attention_scn":
             scores, caps_sorted, decode_lengths, alphas, sort_ind = self.decoder(
                 encoder_out, tags, caps, caplens, prepool=prepool,

@@ -1058,3 +1058,42 @@ def test_reference_loop_body_with_stock_adam(dev):
              "kernel upstream" % (len(g_main), worst_g, worst_noise, len(differing), len(strict)), "reference loop body vs harness path: second-step loss rel err %.3e, max abs parameter "
              "difference %.3e" % (rel_err(loss_b, loss_side), worst)],
             "reference loop body with stock torch.optim.Adam")
+
+
+def test_tagger_beside_the_encoder_gives_the_same_step(dev):
+    """trains/harness.py: with a tagger in the step (trains/attention_scn.py:194,214) its forward pass runs on the side
+    stream beside the caption encoder's (per-stream scratch buffers, event-ordered hand-over of the tags).  Same
+    weights, same batch, against the in-line order.  The comparison cannot be bit-exact: the two trunks then run
+    through different MIOpen handles (one per stream, each with its own find result for the stem and the 3x3 weight
+    gradients), and a randomly initialised 152-layer trunk amplifies a last-bit difference a thousandfold (its OWN
+    run-to-run spread on one stream is 2-4e-4, because the statistics epilogue is shifted by the running mean, which
+    moves every call).  So: losses of two steps within 5e-3, parameters within the 2 * steps * lr of an Adam
+    trajectory, tagger statistics within 1e-3 -- a tag tensor read before it was written, or scratch shared between
+    the two streams, is an O(1) error in the loss."""
+    from trains.harness import TrainStep, synthetic_batch
+    res = {}
+    for overlap in (False, True, True):
+        ts = TrainStep(device=dev, tagger=True, tagger_overlap=overlap, seed=77, batch_size=4, max_len=8, vocab_size=300,
+                       image_size=96)
+        cfg = ts.cfg
+        imgs, tags, caps, caplens = synthetic_batch(4, cfg["vocab_size"], cfg["max_len"], cfg["image_size"],
+                                                    cfg["semantic_dim"], torch.device(dev), 3, ragged=True)
+        torch.manual_seed(11)          # dropout masks of the tagger / decoder
+        losses = [ts.step(imgs, tags, caps, caplens).detach().clone() for _ in range(2)]
+        key = "overlap" if overlap else "inline"
+        cur = (losses, {k: p.detach().clone() for k, p in ts.decoder.named_parameters()},
+               {k: b.detach().clone() for k, b in ts.tagger.named_buffers() if k.endswith("running_mean")})
+        if key in res:       # second overlapped run: the side stream is warm, buffers are being reused
+            key = "overlap2"
+        res[key] = cur
+    rep = []
+    for key in ("overlap", "overlap2"):
+        for i, (a_, b_) in enumerate(zip(res["inline"][0], res[key][0])):
+            rep.append("%s: loss of step %d  %.6f vs in-line %.6f" % (key, i + 1, b_.item(), a_.item()))
+            _ok(b_, a_, 5e-3, "loss (%s)" % key)
+        for k in res["inline"][1]:
+            err = (res["inline"][1][k] - res[key][1][k]).abs().max().item()
+            assert err <= 2 * 2 * 4e-4 * 1.01, "%s (%s): %.3e" % (k, key, err)
+        for k in res["inline"][2]:
+            assert rel_err(res[key][2][k], res["inline"][2][k]) <= 1e-3, "tagger statistics %s differ (%s)" % (k, key)
+    _report(rep, "tagger forward on the side stream beside the caption encoder vs in line")
