@@ -526,7 +526,7 @@ def test_fused_bottleneck_vs_fp64(dev, name, inplanes, planes, stride, H, small,
         SC.ENABLED = fused
         # identity blocks: conv3 == "hip" -> the whole-block C drivers (scnattn_block_fwd/bwd), "miopen" -> the per-call
         # path with MIOpen's conv2; blocks with a downsample branch always take the per-call path
-        saved_driver = SC.C_DRIVER
+        saved_driver, saved_conv3 = SC.C_DRIVER, SC.CONV3
         SC.C_DRIVER = conv3 == "hip"
         SC.CONV3 = conv3        # conv2: the implicit-GEMM 3x3 mode of csrc/cgemm.hip (forward + stride-1 d input) or MIOpen
         try:
@@ -536,7 +536,7 @@ def test_fused_bottleneck_vs_fp64(dev, name, inplanes, planes, stride, H, small,
             torch.cuda.synchronize()
         finally:
             SC.ENABLED = True
-            SC.CONV3 = "auto"
+            SC.CONV3 = saved_conv3
             SC.C_DRIVER = saved_driver
         res[fused] = (y.detach(), xg.grad.detach(), {k: p.grad.detach() for k, p in g.named_parameters()},
                       {k: b.detach().clone() for k, b in g.named_buffers()})
