@@ -1097,3 +1097,34 @@ def test_tagger_beside_the_encoder_gives_the_same_step(dev):
         for k in res["inline"][2]:
             assert rel_err(res[key][2][k], res["inline"][2][k]) <= 1e-3, "tagger statistics %s differ (%s)" % (k, key)
     _report(rep, "tagger forward on the side stream beside the caption encoder vs in line")
+
+
+def test_conv3_autotune_mode(dev):
+    """SCNATTN_CONV3=auto, the product default (the tests otherwise pin "hip", conftest.py): the first call of a shape
+    times the hand-written 3x3 convolution against MIOpen and records a choice per (kind, shape); whatever it picks,
+    the block's output and gradients agree with the pinned-"hip" run to fp32 accuracy."""
+    import copy
+    from scnattn.resnet import Bottleneck
+    from scnattn import conv as SC
+    torch.manual_seed(4)
+    blk = Bottleneck(1024, 256).to(dev).to(memory_format=torch.channels_last).train()
+    x = torch.randn(4, 1024, 8, 8, device=dev).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(4, 1024, 8, 8, device=dev).contiguous(memory_format=torch.channels_last)
+    saved = SC.CONV3
+    res = {}
+    try:
+        for mode in ("hip", "auto"):
+            SC.CONV3 = mode
+            m = copy.deepcopy(blk)
+            xg = x.clone().requires_grad_(True)
+            y = m(xg)
+            (y * w).sum().backward()
+            res[mode] = (y.detach(), xg.grad.detach(), {k: p.grad.detach() for k, p in m.named_parameters()})
+        choices = {k: v for k, v in SC.conv3_choices().items() if k[1:4] == (4, 8, 8)}
+        assert {k[0] for k in choices} == {"fwd", "dgrad"} and set(choices.values()) <= {"hip", "miopen"}, choices
+    finally:
+        SC.CONV3 = saved
+    _ok(res["auto"][0], res["hip"][0], 1e-5, "output")
+    _ok(res["auto"][1], res["hip"][1], 1e-4, "d x")
+    for k in res["hip"][2]:
+        _ok(res["auto"][2][k], res["hip"][2][k], 1e-4, k)
