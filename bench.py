@@ -203,6 +203,8 @@ def main():
     ap.add_argument("--dtype", default=None, choices=["f32", "bf16"],
                     help="shorthand: bf16 = --encoder-dtype bf16 --decoder-dtype bf16 (BASELINE configs[4] flavour, a "
                          "second line next to the fp32 headline)")
+    ap.add_argument("--host-lengths", action="store_true",
+                    help="A/B: caption lengths also as a CPU tensor -> no host sync in the decoder's forward pass (measured slower)")
     ap.add_argument("--no-tagger-overlap", action="store_true",
                     help="A/B (--with-tagger): the tagger's forward pass in line on the main stream instead of beside the "
                          "caption encoder's on the side stream")
@@ -320,6 +322,11 @@ def main():
         batches = hdf5_batches(args, cfg, dev, rank, world)
 
     last_loss = [None]
+    # --host-lengths (experiment): hand the decoder the caption lengths as a CPU tensor too, so that its forward pass
+    # needs no device synchronisation to learn its loop bounds.  Measured SLOWER (785-790 vs 805-807 images/s): the one
+    # sync per step (the reference's own `.tolist()`, attention_scn.py:131) keeps the host from running so far ahead
+    # that blocks the side stream still holds cannot be reused and the caching allocator has to hipMalloc.
+    caplens_host = caplens.cpu() if (args.host_lengths and batches is None) else None
 
     def run(n):
         nonlocal imgs, caps, caplens
@@ -331,7 +338,8 @@ def main():
                     ts.decoder(enc_in, tags, caps, caplens, prepool=pre_in) if pre_in is not None else \
                         ts.decoder(enc_in, tags, caps, caplens)
             else:
-                last_loss[0] = ts.step(imgs, tags, caps, caplens, enc_in, pre_in, drop_in=drop_in[0])
+                last_loss[0] = ts.step(imgs, tags, caps, caplens, enc_in, pre_in, drop_in=drop_in[0],
+                                       caplens_host=caplens_host)
 
     drop_in = [bool(args.drop_in_call)]
     dbg = (lambda m: print("[bench] " + m, file=sys.stderr, flush=True)) if os.environ.get("BENCH_DEBUG") else (lambda m: None)

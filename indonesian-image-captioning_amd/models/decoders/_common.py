@@ -8,22 +8,31 @@ from scnattn import functional as SF
 from utils.token import start_token, end_token
 
 
-def sort_by_length(encoder_out, encoded_captions, caption_lengths, sort_ind=None):
+def sort_by_length(encoder_out, encoded_captions, caption_lengths, sort_ind=None, caplens_host=None):
     """Flatten pixels, sort rows by caption length (descending) and permute images + captions.
     Tags are deliberately NOT touched (the reference indexes the un-permuted tags, :152).
-    Returns enc (B,P,E), caps (B,L), decode_lengths (list[int]), sort_ind."""
+    Returns enc (B,P,E), caps (B,L), decode_lengths (list[int]), sort_ind.
+    `caplens_host`: the same caption lengths as a CPU tensor, when the caller has them there anyway (a loader reads
+    them from a JSON file): the Python list the loop bounds come from is then computed on the host and the forward
+    pass has NO device synchronisation at all -- the host keeps running ahead of the GPU across the encoder / decoder
+    boundary.  Without it: one sync, exactly where the reference has its `.tolist()` (:131)."""
     B, E = encoder_out.size(0), encoder_out.size(-1)
     enc = encoder_out.reshape(B, -1, E)
     lens = caption_lengths.squeeze(1)
-    if sort_ind is None:
+    sort_given = sort_ind is not None
+    if not sort_given:
         lens, sort_ind = lens.sort(dim=0, descending=True, stable=True)
     else:
         lens = lens[sort_ind]
-    # the one host sync of the forward pass, as in the reference (`.tolist()`, :131); the permutation rides
-    # along so that a batch that is already in order (fixed-length captions, or a loader that sorts) skips
-    # the 51 MB gather of encoder_out and, when the encoder is fine-tuned, its scatter in the backward pass
-    host = torch.stack([lens - 1, sort_ind]).tolist()
-    decode_lengths, perm = host
+    if caplens_host is not None and not sort_given:
+        lh, ph = caplens_host.reshape(-1).cpu().sort(dim=0, descending=True, stable=True)    # same stable order as on the device
+        decode_lengths, perm = (lh - 1).tolist(), ph.tolist()
+    else:
+        # the one host sync of the forward pass, as in the reference (`.tolist()`, :131); the permutation rides
+        # along so that a batch that is already in order (fixed-length captions, or a loader that sorts) skips
+        # the 51 MB gather of encoder_out and, when the encoder is fine-tuned, its scatter in the backward pass
+        host = torch.stack([lens - 1, sort_ind]).tolist()
+        decode_lengths, perm = host
     if perm != list(range(B)):
         enc = enc[sort_ind]
         encoded_captions = encoded_captions[sort_ind]

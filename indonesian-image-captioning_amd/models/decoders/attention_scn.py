@@ -60,7 +60,7 @@ class AttentionSCN(nn.Module):
         return h, c
 
     def forward(self, encoder_out, semantic_input, encoded_captions, caption_lengths, sort_ind=None, prepool=None,
-                pool_size=14):
+                pool_size=14, caplens_host=None):
         """Reference signature (attention_scn.py:95) plus optional extras.  `prepool`: the encoder trunk's map
         (B, h, w, E) of which `encoder_out` is the AdaptiveAvgPool2d(pool_size) (models/encoders/caption.py:41-43);
         given it -- explicitly, or attached by this build's EncoderCaption to the tensor it returned -- the
@@ -68,7 +68,7 @@ class AttentionSCN(nn.Module):
         SURVEY 8d); `encoder_out` may then be None."""
         src, pool = _common.resolve_prepool(encoder_out, prepool, pool_size, self.attention_dim, "AttentionSCN.forward")
         enc, caps, decode_lengths, dl_dev, sort_ind = _common.sort_by_length(
-            src, encoded_captions, caption_lengths, sort_ind)
+            src, encoded_captions, caption_lengths, sort_ind, caplens_host)
         B, E = enc.shape[0], enc.shape[2]
         P = pool.P if pool is not None else enc.shape[1]
         T = max(decode_lengths)

@@ -76,10 +76,11 @@ class PureAttention(nn.Module):
         named = dict(self.named_parameters())
         return [scn[f] if f in scn else named.get(_KEY_OF_FIELD[f]) for f in PARAM_FIELDS]
 
-    def forward(self, encoder_out, encoded_captions, caption_lengths, sort_ind=None, prepool=None, pool_size=14):
+    def forward(self, encoder_out, encoded_captions, caption_lengths, sort_ind=None, prepool=None, pool_size=14,
+                caplens_host=None):
         src, pool = _common.resolve_prepool(encoder_out, prepool, pool_size, self.attention_dim, "PureAttention.forward")
         enc, caps, decode_lengths, dl_dev, sort_ind = _common.sort_by_length(
-            src, encoded_captions, caption_lengths, sort_ind)
+            src, encoded_captions, caption_lengths, sort_ind, caplens_host)
         B, E = enc.shape[0], enc.shape[2]
         P = pool.P if pool is not None else enc.shape[1]
         T = max(decode_lengths)

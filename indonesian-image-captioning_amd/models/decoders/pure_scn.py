@@ -44,13 +44,13 @@ class PureSCN(nn.Module):
                 SF.linear(mean_encoder_out, self.init_c.weight, self.init_c.bias))
 
     def forward(self, encoder_out, semantic_input, encoded_captions, caption_lengths, sort_ind=None, prepool=None,
-                pool_size=14):
+                pool_size=14, caplens_host=None):
         """Reference signature (pure_scn.py:87) plus the optional trunk map (see AttentionSCN.forward): only the
         initial state reads the encoder output here, and the pixel mean of the pooled map is a weighted mean of
         the un-pooled one."""
         src, pool = _common.resolve_prepool(encoder_out, prepool, pool_size, None, "PureSCN.forward")
         enc, caps, decode_lengths, dl_dev, sort_ind = _common.sort_by_length(
-            src, encoded_captions, caption_lengths, sort_ind)
+            src, encoded_captions, caption_lengths, sort_ind, caplens_host)
         B, E = enc.shape[0], enc.shape[2]
         P = pool.P if pool is not None else enc.shape[1]
         T = max(decode_lengths)

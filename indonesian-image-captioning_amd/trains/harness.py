@@ -139,11 +139,13 @@ class TrainStep:
             loss = loss + self.cfg["alpha_c"] * ((1. - alphas.sum(dim=1)) ** 2).mean()
         return loss
 
-    def step(self, imgs, tags, caps, caplens, encoder_out=None, prepool=None, drop_in=False):
+    def step(self, imgs, tags, caps, caplens, encoder_out=None, prepool=None, drop_in=False, caplens_host=None):
         """`drop_in=True` is the reference's literal call sequence (trains/attention_scn.py:213-216):
         `encoder_out = encoder(imgs)` materialises the (B,14,14,2048) map, `decoder(encoder_out, ...)` receives only
         that tensor (and finds the trunk map EncoderCaption attached to it).  The default hands the trunk map over
-        explicitly and skips the pooling kernel and its 51 MB write."""
+        explicitly and skips the pooling kernel and its 51 MB write.  `caplens_host`: the caption lengths as a CPU tensor
+        when the caller has them on the host anyway (a loader does): the decoder then needs no device synchronisation
+        to learn its loop bounds (models/decoders/_common.py::sort_by_length); ignored for `drop_in`."""
         tag_event = None
         if self.tagger is not None and self.tagger_overlap and imgs.is_cuda and self.encoder is not None:
             # The frozen tagger's forward pass shares nothing with the caption encoder's: it runs on the side stream
@@ -175,16 +177,19 @@ class TrainStep:
         if self.kind == "attention_scn":
             scores, caps_sorted, decode_lengths, alphas, sort_ind = self.decoder(
                 encoder_out, tags, caps, caplens, prepool=prepool,
-                pool_size=self.encoder.enc_image_size if self.encoder is not None else 14)
+                pool_size=self.encoder.enc_image_size if self.encoder is not None else 14,
+                caplens_host=None if drop_in else caplens_host)
         elif self.kind == "pure_scn":
             scores, caps_sorted, decode_lengths, sort_ind = self.decoder(
                 encoder_out, tags, caps, caplens, prepool=prepool,
-                pool_size=self.encoder.enc_image_size if self.encoder is not None else 14)
+                pool_size=self.encoder.enc_image_size if self.encoder is not None else 14,
+                caplens_host=None if drop_in else caplens_host)
             alphas = None
         else:
             scores, caps_sorted, decode_lengths, alphas, sort_ind = self.decoder(
                 encoder_out, caps, caplens, prepool=prepool,
-                pool_size=self.encoder.enc_image_size if self.encoder is not None else 14)
+                pool_size=self.encoder.enc_image_size if self.encoder is not None else 14,
+                caplens_host=None if drop_in else caplens_host)
         dl_dev = (caplens.reshape(-1)[sort_ind] - 1).to(torch.int32) if self.fused_loss else None
         loss = self.loss_fn(scores, caps_sorted, decode_lengths, alphas, dl_dev)
         self.decoder_optimizer.zero_grad()
