@@ -353,9 +353,16 @@ def main():
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
+    ms0 = torch.cuda.memory_stats(dev)
     t0 = time.perf_counter()
     run(args.steps)
     torch.cuda.synchronize()
+    ms1 = torch.cuda.memory_stats(dev)
+    # device allocations (hipMalloc) inside the timed region: each one stalls the device
+    alloc_stats = {"segments_allocated_in_timed_region": int(ms1.get("segment.all.allocated", 0) - ms0.get("segment.all.allocated", 0)),
+                   "alloc_retries_in_timed_region": int(ms1.get("num_alloc_retries", 0) - ms0.get("num_alloc_retries", 0)),
+                   "reserved_GiB": round(ms1.get("reserved_bytes.all.current", 0) / 2**30, 2)}
+    dbg("allocator: %r" % (alloc_stats,))
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
@@ -433,6 +440,7 @@ def main():
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world,
                        "call_sequence": "drop-in: encoder(imgs) -> decoder(encoder_out, ...)" if args.drop_in_call else
                        "harness: encoder(imgs, pooled=False) -> decoder(None, ..., prepool=trunk map)"},
+            "allocator": alloc_stats,
             "rccl_world_size": dist.get_world_size() if dist_on else 1,
             "dp_backend": (args.dp_backend if dist_on else None),
         }
