@@ -515,7 +515,11 @@ def main():
                                    "avg_us": round(ctx_us, 2),
                                    "achieved_GBs": round(ctx_bytes / ctx_per_step / (ctx_us * 1e-6) / 1e9, 1),
                                    "frac": round(ctx_bytes / ctx_per_step / (ctx_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                   "note": None if ctx_per_step < 1.5 else
+                                   "note": ("one launch bracketed by two HIP event records on the launch stream, measured in "
+                                            "two extra steps outside the timed region: the bracket adds the processing of "
+                                            "its own two markers (~3 us); rocprofv3's duration of this kernel inside the same "
+                                            "step is 7.3 us (profiles/r02_full_step_kernel_stats_final.csv)")
+                                   if ctx_per_step < 1.5 else
                                    "with 2 chains the two half-batch launches overlap other kernels of the "
                                    "sibling chain, so the per-launch time is not a standalone figure"},
                                "bwd_avg_step_us": round(1e3 * prof[2] / prof[3], 2) if prof[3] > 0 else None}
