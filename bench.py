@@ -197,11 +197,11 @@ def main():
                     help="also run the frozen EncoderTagger ResNet-152 each step (the reference's real step)")
     ap.add_argument("--encoder-dtype", default="f32", choices=["f32", "bf16"],
                     help="bf16: ResNet trunk under bf16 autocast (BASELINE config 5 flavour; not the fp32 headline)")
-    ap.add_argument("--decoder-dtype", default="f32", choices=["f32", "bf16"],
+    ap.add_argument("--decoder-dtype", default="f32", choices=["f32", "bf16", "bf16mfma"],
                     help="bf16: the decode step streams bf16 copies of the recurrent weights, att1 and the trunk map "
                          "(fp32 accumulate / state / master weights / gradients)")
     ap.add_argument("--dtype", default=None, choices=["f32", "bf16"],
-                    help="shorthand: bf16 = --encoder-dtype bf16 --decoder-dtype bf16 (BASELINE configs[4] flavour, a "
+                    help="shorthand: bf16 = --encoder-dtype bf16 --decoder-dtype bf16mfma (BASELINE configs[4] flavour, a "
                          "second line next to the fp32 headline)")
     ap.add_argument("--host-lengths", action="store_true",
                     help="A/B: caption lengths also as a CPU tensor -> no host sync in the decoder's forward pass (measured slower)")
@@ -243,7 +243,8 @@ def main():
                          "(`drop_in_call` in the JSON line) after the harness sequence")
     args = ap.parse_args()
     if args.dtype:
-        args.encoder_dtype = args.decoder_dtype = args.dtype
+        args.encoder_dtype = args.dtype
+        args.decoder_dtype = "bf16mfma" if args.dtype == "bf16" else args.dtype
     os.environ["SCNATTN_DP_BACKEND"] = args.dp_backend
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -425,7 +426,9 @@ def main():
             "dtype": {("f32", "f32"): "f32",
                       ("bf16", "f32"): "bf16 encoder convs (fp32 accumulate/master) + f32 decoder",
                       ("f32", "bf16"): "f32 encoder + bf16-storage decoder step (fp32 accumulate/state/master/gradients)",
-                      ("bf16", "bf16"): "bf16 encoder convs + bf16-storage decoder step (fp32 accumulate/state/master/gradients)"
+                      ("bf16", "bf16"): "bf16 encoder convs + bf16-storage decoder step (fp32 accumulate/state/master/gradients)",
+                      ("f32", "bf16mfma"): "f32 encoder + bf16 decoder step (bf16 operands on the bf16 MFMA, fp32 accumulate/state/master/gradients)",
+                      ("bf16", "bf16mfma"): "bf16 encoder convs + bf16 decoder step (bf16 operands on the bf16 MFMA, fp32 accumulate/state/master/gradients)"
                       }[(args.encoder_dtype, args.decoder_dtype)],
             "data": "synthetic" if args.data == "synthetic" else
             "synthetic %d-image HDF5 split read through scnattn.data.DeviceBatchLoader (%s) inside the timed region"
@@ -463,8 +466,9 @@ def main():
             ach = ab / (step_us * 1e-6) / 1e9
             traffic, tsrc = None, None
             pooled = not args.dense_attention
-            dbf = args.decoder_dtype == "bf16"
-            pmc_name = ("r02_pmc_decode_step_fwd_%s_bf16.json" if dbf else
+            dbf = args.decoder_dtype in ("bf16", "bf16mfma")
+            pmc_name = ("r02_pmc_decode_step_fwd_%s_bf16mfma.json" if args.decoder_dtype == "bf16mfma" else
+                        "r02_pmc_decode_step_fwd_%s_bf16.json" if dbf else
                         "r02_pmc_decode_step_fwd_%s.json" if pooled else "r01_pmc_decode_step_fwd_%s.json") \
                 % ("pooled" if pooled else "dense")
             pmc = os.path.join(ROOT, "profiles", pmc_name)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SCNATTN_VERSION 105 /* 0.1.5: + bf16 storage mode of the sequence drivers, scnattn_seq_bwd_streams */
+#define SCNATTN_VERSION 106 /* 0.1.6: + bf16 modes of the sequence drivers, scnattn_seq_bwd_streams, scnattn_stream_* */
 
 int scnattn_version(void);
 const char* scnattn_last_error(void);
@@ -36,7 +36,7 @@ const char* scnattn_last_error(void);
  * "attn_handoff" (1: on the pooled path the attention scores and the context run as ONE launch whose E-chunk
  * workgroups share the scores of a batch row through an in-launch hand-off; default 0 = two launches: measured equal),
  * "handoff_check" (1: scnattn_seq_fwd synchronises at its end and returns an error if a hand-off wait timed out),
- * "decoder_bf16" (1: the sequence drivers stream bf16 copies of the recurrent weights, att1 and the encoder map --
+ * "decoder_bf16" (1; 2 = the same plus the bf16 matrix instruction in the per-step products: the sequence drivers stream bf16 copies of the recurrent weights, att1 and the encoder map --
  * see scnattn_skinny_gemm_bf16w; needs D, F, E, A multiples of 4, otherwise the fp32 path runs),
  * tuning of the dense / convolution GEMM (csrc/cgemm.hip): "use_cgemm" (0: every product on the round-1 sgemm kernel),
  * "cgemm_mi" (0 auto; 1 / 2 force the 64- / 128-row tile), "cgemm_target" (workgroups a split-K product aims for, 512),
@@ -181,6 +181,11 @@ int scnattn_skinny_gemm(void* stream, int rows, int N, int K, int groups, const 
 int scnattn_skinny_gemm_bf16w(void* stream, int rows, int N, int K, int groups, const float* X, long ldx, long xg,
                               const void* W_bf16, long ldw, long wg, float* Y, long ldy, long yg, long yslab,
                               int ksplit, int* ksplit_out);
+/* ... and with the activation rows rounded to bf16 in registers as well: v_mfma_f32_32x32x16_bf16, fp32 accumulation
+ * (option "decoder_bf16" = 2 selects it inside the sequence drivers) */
+int scnattn_skinny_gemm_bf16(void* stream, int rows, int N, int K, int groups, const float* X, long ldx, long xg,
+                             const void* W_bf16, long ldw, long wg, float* Y, long ldy, long yg, long yslab,
+                             int ksplit, int* ksplit_out);
 int scnattn_f32_to_bf16(void* stream, long n, const float* in, void* out);
 
 /* HIP streams with an explicit priority for hosts whose framework cannot create them (PyTorch exposes only "normal" and

@@ -62,7 +62,7 @@ int scnattn_set_option(const char* name, int value) {
     }
     if (name && std::strcmp(name, "attn_depth") == 0) { g_attn_depth = value != 0; return 0; }
     if (name && std::strcmp(name, "attn_handoff") == 0) { g_attn_handoff = value != 0; return 0; }
-    if (name && std::strcmp(name, "decoder_bf16") == 0) { g_dec_bf16 = value != 0; return 0; }
+    if (name && std::strcmp(name, "decoder_bf16") == 0 && value >= 0 && value <= 2) { g_dec_bf16 = value; return 0; }
     if (name && std::strcmp(name, "handoff_check") == 0) { g_handoff_check = value != 0; return 0; }
     if (name && std::strcmp(name, "gemm_target") == 0 && value >= 1) { g_gemm_target = value; return 0; }
     if (name && std::strcmp(name, "gemm_gate") == 0 && value >= 1) { g_gemm_gate = value; return 0; }
@@ -247,7 +247,7 @@ int scnattn_skinny_gemm_bf16w(void* stream, int rows, int N, int K, int groups, 
                               int ksplit, int* ksplit_out) {
     if (ksplit <= 0) ksplit = skinny_pick_ksplit(rows, N, K, groups);
     if (ksplit_out) *ksplit_out = ksplit;
-    return skinny_gemm(ST(stream), rows, N, K, groups, X, ldx, xg, W_bf16, ldw, wg, Y, ldy, yg, yslab, ksplit, true);
+    return skinny_gemm(ST(stream), rows, N, K, groups, X, ldx, xg, W_bf16, ldw, wg, Y, ldy, yg, yslab, ksplit, 1);
 }
 
 int scnattn_stream_priority_range(int* least, int* greatest) {
@@ -269,6 +269,14 @@ int scnattn_stream_create(int priority, void** out) {
 int scnattn_stream_destroy(void* stream) {
     if (stream) SCN_HIP(hipStreamDestroy(ST(stream)));
     return 0;
+}
+
+int scnattn_skinny_gemm_bf16(void* stream, int rows, int N, int K, int groups, const float* X, long ldx, long xg,
+                             const void* W_bf16, long ldw, long wg, float* Y, long ldy, long yg, long yslab,
+                             int ksplit, int* ksplit_out) {
+    if (ksplit <= 0) ksplit = skinny_pick_ksplit(rows, N, K, groups);
+    if (ksplit_out) *ksplit_out = ksplit;
+    return skinny_gemm(ST(stream), rows, N, K, groups, X, ldx, xg, W_bf16, ldw, wg, Y, ldy, yg, yslab, ksplit, 2);
 }
 
 int scnattn_f32_to_bf16(void* stream, long n, const float* in, void* out) { return f32_to_bf16(ST(stream), n, in, out); }

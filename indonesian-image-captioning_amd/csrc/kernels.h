@@ -44,9 +44,10 @@ int cgemm_row_tiles(int M);
 
 // ---- skinny.hip ------------------------------------------------------------------------------
 int skinny_pick_ksplit(int rows, int N, int K, int groups);
-// wbf: W holds bf16 (raw 16-bit) elements, ldw / wg still count elements
+// wbf 1: W holds bf16 (raw 16-bit) elements, ldw / wg still count elements; 2: X is rounded to bf16 in registers too and
+// the products run on the bf16 matrix instruction (fp32 accumulation)
 int skinny_gemm(hipStream_t st, int rows, int N, int K, int groups, const float* X, long ldx, long xg,
-                const void* W, long ldw, long wg, float* Y, long ldy, long yg, long yslab, int ksplit, bool wbf = false);
+                const void* W, long ldw, long wg, float* Y, long ldy, long yg, long yslab, int ksplit, int wbf = 0);
 
 // A split-K result: `n` slabs `stride` elements apart, row leading dimension `ld`.
 struct Slabs {

@@ -31,7 +31,7 @@ int g_fuse_attn = 0;     // 1: scores+softmax+context+gate as one launch (measur
                          //    each E-chunk workgroup recomputes all 196 scores through its CU's L2 port)
 extern int g_attn_handoff;   // 1: pooled path runs scores + context as one launch with an in-launch hand-off (default 0: not faster)
 int g_handoff_check = 0;     // 1: seq_fwd synchronises at its end and reports a hand-off time-out (tests)
-int g_dec_bf16 = 0;          // 1: BASELINE configs[4] flavour -- the operands the recurrence STREAMS every step (recurrent
+int g_dec_bf16 = 0;          // 1 (2: + bf16 matrix instruction in the skinny GEMMs): BASELINE configs[4] flavour -- the operands the recurrence STREAMS every step (recurrent
                              //    weights, att1, the encoder map) are kept as bf16 copies, made once per call; products
                              //    accumulate in fp32, softmax / LSTM state / master weights / every gradient stay fp32
 
@@ -364,6 +364,7 @@ int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
     }
 
     const bool bf = bf16_mode(d);
+    const int bfm = bf ? (g_dec_bf16 >= 2 ? 2 : 1) : 0;     // 2: the skinny products on the bf16 matrix instruction
     if (bf) {
         SCN_TRY(f32_to_bf16(st, sz(D, NA), f.WcatA, f.WcatAh));
         SCN_TRY(f32_to_bf16(st, sz(4, 2 * F, D), f.WD, f.WDh));
@@ -425,7 +426,7 @@ int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
             const float* h = s.Hs + rowT * D;
             const float* c = s.Cs + rowT * D;
             const int ksA = pick(bt_, NA, D, 1);
-            SCN_TRY(skinny_gemm(cs, bt_, NA, D, 1, h, D, 0, WcatA, NA, 0, slabA, NA, 0, (long)B * NA, ksA, bf));
+            SCN_TRY(skinny_gemm(cs, bt_, NA, D, 1, h, D, 0, WcatA, NA, 0, slabA, NA, 0, (long)B * NA, ksA, bfm));
             Slabs pz{nullptr, 0, 0, 0};
             if (d.has_att) {
                 float* alpha_out = alphas + (long)r0 * T * P + (long)t * P;
@@ -470,14 +471,14 @@ int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
                 }
                 const int ksC = pick(bt_, F4, E, 1);
                 SCN_TRY(skinny_gemm(cs, bt_, F4, E, 1, s.z_all + rowT * E, E, 0, WaM, F4, 0, slabC, F4, 0, (long)B * F4, ksC,
-                                    bf));
+                                    bfm));
                 pz = Slabs{slabC, ksC, (long)B * F4, F4};
             }
             SCN_TRY(scn_mix_fwd(cs, bt_, F4, pz, s.ex + rowT * F4, Slabs{slabA + colph, ksA, (long)B * NA, NA}, qx, qh,
                                 s.pa_all + rowT * F4, s.ph_all + rowT * F4, xcat));
             const int ksD = pick(bt_, D, 2 * F, 4);
             SCN_TRY(skinny_gemm(cs, bt_, D, 2 * F, 4, xcat, 8 * F, 2 * F, WD, D, (long)2 * F * D, slabD, D, BD, 4 * BD,
-                                ksD, bf));
+                                ksD, bfm));
             SCN_TRY(lstm_fwd(cs, bt_, D, Slabs{slabD, ksD, 4 * BD, D}, BD, w->decode_step_bias_ih,
                              w->decode_step_bias_hh, c, s.gates_all + rowT * 4 * D, s.Cs + (rowT + B) * D,
                              s.Hs + (rowT + B) * D, s.tanhc_all + rowT * D));
@@ -563,6 +564,7 @@ int seq_bwd(hipStream_t st, hipStream_t wst, const scnattn_dims* dp, const scnat
         SCN_TRY(copy2d(st, A, D, w->attention_decoder_att_weight, D, k.WcatT + (long)(F4 + E) * D, D));
     }
     const bool bf = bf16_mode(d);
+    const int bfm = bf ? (g_dec_bf16 >= 2 ? 2 : 1) : 0;     // 2: the skinny products on the bf16 matrix instruction
     if (bf) {
         SCN_TRY(f32_to_bf16(st, sz(4, D, 2 * F), k.WDb, k.WDbh));
         SCN_TRY(f32_to_bf16(st, sz(NC, D), k.WcatT, k.WcatTh));
@@ -606,12 +608,12 @@ int seq_bwd(hipStream_t st, hipStream_t wst, const scnattn_dims* dp, const scnat
                              s.Cs + rowT * D, s.tanhc_all + rowT * D, dr));
             const int ksDb = pick(bt_, 2 * F, D, 4);
             SCN_TRY(skinny_gemm(cs, bt_, 2 * F, D, 4, dr, 4 * D, D, WDb, 2 * F, (long)D * 2 * F, sDb, 2 * F,
-                                (long)B * 2 * F, (long)4 * B * 2 * F, ksDb, bf));
+                                (long)B * 2 * F, (long)4 * B * 2 * F, ksDb, bfm));
             SCN_TRY(scn_mix_bwd(cs, bt_, F4, Slabs{sDb, ksDb, (long)4 * B * 2 * F, 2 * F}, (long)B * 2 * F, qx, qh,
                                 s.pa_all + rowT * F4, s.ph_all + rowT * F4, dpx, dcat, NC, dqx_acc, dqh_acc));
             if (d.has_att) {
                 const int ksZ = pick(bt_, E, F4, 1);
-                SCN_TRY(skinny_gemm(cs, bt_, E, F4, 1, dpx, F4, 0, WaTz, E, 0, sZ, E, 0, (long)B * E, ksZ, bf));
+                SCN_TRY(skinny_gemm(cs, bt_, E, F4, 1, dpx, F4, 0, WaTz, E, 0, sZ, E, 0, (long)B * E, ksZ, bfm));
                 float* dawe = k.dawe_all + rowT * E;
                 SCN_TRY(gate_bwd(cs, bt_, E, Slabs{sZ, ksZ, (long)B * E, E}, s.awe_all + rowT * E,
                                  s.gate_all + rowT * E, dawe, dcat + F4, NC));
@@ -630,7 +632,7 @@ int seq_bwd(hipStream_t st, hipStream_t wst, const scnattn_dims* dp, const scnat
                 }
             }
             ksH = pick(bt_, D, NC, 1);
-            SCN_TRY(skinny_gemm(cs, bt_, D, NC, 1, dcat, NC, 0, WcatT, D, 0, sH, D, 0, BD, ksH, bf));
+            SCN_TRY(skinny_gemm(cs, bt_, D, NC, 1, dcat, NC, 0, WcatT, D, 0, sH, D, 0, BD, ksH, bfm));
             tlast = t;
         }
         // d loss / d h0 for this chain's rows (d/d c0 is k.dc); every row decodes at t = 0

@@ -45,7 +45,11 @@ struct SkinnyArgs {
 // NB = 8-k blocks per wave per chunk (compile-time so that every loop below is branch-free: a run-time
 // bound makes hipcc sink the loads of the optional blocks next to their MFMAs, each behind a vmcnt(0)).
 // WBF: the weights are stored as bf16 (2-byte loads, widened in registers); fp32 MFMA and accumulation either way.
-template <int NB, bool XVEC, bool WBF>
+// BFM (with WBF): the activation fragment is rounded to bf16 in registers as well and the products run on
+// v_mfma_f32_32x32x16_bf16 (fp32 accumulation): 4 matrix instructions per 64 k instead of 32 -- the usual mixed-precision
+// contract (both operands bf16).  Lane (r = l&31, h = l>>5) holds X[r][k0 + 8h .. +7] and W[k0 + 8h + j][n0 + r].
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+template <int NB, bool XVEC, bool WBF, bool BFM = false>
 __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
     __shared__ float red[4][32 * XLD];
 
@@ -77,6 +81,46 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
+    if constexpr (BFM) {      // NB even (host): NB/2 blocks of 16 k
+        for (int c0 = 0; c0 < per; c0 += 8 * NB) {
+            const int kw0 = kbeg + wave * per + c0;
+            unsigned short wr16[NB / 2][8];
+            f32x4 xv[NB / 2][2];
+#pragma unroll
+            for (int j = 0; j < NB / 2; ++j) {
+                const unsigned k = (unsigned)(kw0 + 16 * j + 8 * kk);
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    wr16[j][c] = __builtin_amdgcn_raw_buffer_load_b16(wr, nok ? (k + c) * ldw4 + wcol : OOB_OFF, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < NB / 2; ++j) {
+                const int k = kw0 + 16 * j + 8 * kk;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int kq = k + 4 * q;
+                    if (XVEC) {
+                        xv[j][q] = buf_load4(xr, (rok && kq < kend) ? xrow + (unsigned)kq * 4u : OOB_OFF);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            xv[j][q][c] = buf_load(xr, (rok && kq + c < kend) ? xrow + (unsigned)(kq + c) * 4u : OOB_OFF);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NB / 2; ++j) {
+                bf16x8_t af, bfv;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    af[c] = (__bf16)xv[j][c >> 2][c & 3];
+                    bfv[c] = __builtin_bit_cast(__bf16, wr16[j][c]);
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfv, acc, 0, 0, 0);
+            }
+        }
+    } else
     for (int c0 = 0; c0 < per; c0 += 8 * NB) {         // per is a multiple of 8*NB (host guarantees it)
         const int kw0 = kbeg + wave * per + c0;        // first k of this wave's chunk
         // every load of the chunk is issued before the first MFMA
@@ -144,7 +188,7 @@ int skinny_pick_ksplit(int rows, int N, int K, int groups) {
 }
 
 int skinny_gemm(hipStream_t st, int rows, int N, int K, int groups, const float* X, long ldx, long xg,
-                const void* W, long ldw, long wg, float* Y, long ldy, long yg, long yslab, int ksplit, bool wbf) {
+                const void* W, long ldw, long wg, float* Y, long ldy, long yg, long yslab, int ksplit, int wbf) {
     if (rows <= 0 || N <= 0 || groups <= 0) return 0;
     SCN_ARG(X && W && Y, "skinny_gemm: null operand");
     SCN_ARG(K >= 1, "skinny_gemm: K must be >= 1");
@@ -153,6 +197,7 @@ int skinny_gemm(hipStream_t st, int rows, int N, int K, int groups, const float*
             "skinny_gemm: operand exceeds the 2 GiB buffer-descriptor range");
     int per = cdiv(cdiv(K, ksplit), 4);      // k per wave
     per = (per + 7) & ~7;                    // whole 8-k blocks
+    if (wbf == 2) per = (per + 15) & ~15;    // bf16 matrix instruction: whole 16-k blocks
     if (per > KW) per = (per + KW - 1) / KW * KW;   // several full chunks
     const int nb = per > KW ? NBW : per / 8;
     const int kslice = 4 * per;
@@ -161,7 +206,10 @@ int skinny_gemm(hipStream_t st, int rows, int N, int K, int groups, const float*
     dim3 grid(cdiv(N, 32) * groups, ksplit, cdiv(rows, 32)), block(256);
 #define SCN_SKINNY_CASE(NB_)                                                                     \
     case NB_:                                                                                     \
-        if (wbf) {                                                                                \
+        if (wbf == 2 && (NB_ % 2) == 0) {                                                         \
+            if (xvec) hipLaunchKernelGGL((skinny_kernel<(NB_ % 2 ? NB_ + 1 : NB_), true, true, true>), grid, block, 0, st, a);   \
+            else      hipLaunchKernelGGL((skinny_kernel<(NB_ % 2 ? NB_ + 1 : NB_), false, true, true>), grid, block, 0, st, a);  \
+        } else if (wbf) {                                                                         \
             if (xvec) hipLaunchKernelGGL((skinny_kernel<NB_, true, true>), grid, block, 0, st, a);    \
             else      hipLaunchKernelGGL((skinny_kernel<NB_, false, true>), grid, block, 0, st, a);   \
         } else {                                                                                  \

@@ -75,9 +75,9 @@ class TrainStep:
         # read as bf16 copies made once per call (include/scnattn.h, option "decoder_bf16"); fp32 accumulate, fp32
         # softmax / LSTM state / master weights / gradients.  A process-wide option of the library.
         self.tagger_overlap = tagger_overlap
-        self.decoder_bf16 = decoder_dtype == "bf16"
-        if torch.device(device).type == "cuda":
-            SF.set_option("decoder_bf16", 1 if self.decoder_bf16 else 0)
+        self.decoder_bf16 = decoder_dtype in ("bf16", "bf16mfma")
+        if torch.device(device).type == "cuda":      # "bf16mfma": also round the activation rows of the per-step products
+            SF.set_option("decoder_bf16", {"bf16": 1, "bf16mfma": 2}.get(decoder_dtype, 0))   # and use the bf16 MFMA
         self.device = torch.device(device)
         torch.manual_seed(seed)  # same seed on every rank => identical initial weights
         self.decoder = build_decoder(kind, self.cfg).to(self.device)

@@ -759,11 +759,20 @@ def test_f32_to_bf16_and_bf16_weight_skinny_gemm(dev):
         got = Y[:used.value].double().sum(0)                                     # (groups, rows, N)
         want = torch.einsum("rgk,gkn->grn", X.view(rows, groups, K).double(), Wh.double())
         _ok(got, want, 1e-5, "skinny bf16w %s" % ((rows, N, K, groups),))
+        # both operands bf16 on v_mfma_f32_32x32x16_bf16: against fp64 on the SAME rounded operands (the kernel rounds X
+        # to nearest even in registers, as torch's conversion does); bf16 x bf16 products are exact in fp32
+        Y.zero_()
+        call("scnattn_skinny_gemm_bf16", stream_of(X), rows, N, K, groups, ptr(X), groups * K, K, ptr(Wh), N, K * N, ptr(Y),
+             N, rows * N, groups * rows * N, 0, C.byref(used))
+        got = Y[:used.value].double().sum(0)
+        want = torch.einsum("rgk,gkn->grn", X.to(torch.bfloat16).view(rows, groups, K).double(), Wh.double())
+        _ok(got, want, 1e-5, "skinny bf16 mfma %s" % ((rows, N, K, groups),))
 
 
+@pytest.mark.parametrize("mode", [1, 2], ids=["storage", "mfma"])
 @pytest.mark.parametrize("kind,ragged,pooled", [("attention_scn", True, True), ("attention_scn", False, True),
                                                 ("attention_scn", True, False), ("pure_scn", True, True)])
-def test_bf16_storage_decoder_vs_oracle(dev, kind, ragged, pooled):
+def test_bf16_storage_decoder_vs_oracle(dev, kind, ragged, pooled, mode):
     """Option "decoder_bf16": the operands the recurrence streams (recurrent weights, att1, the trunk map) are bf16
     copies, everything else fp32.  Against the fp64 oracle at full width: a bf16 element carries 8 significant bits
     (relative rounding 2^-9 = 2e-3); outputs and gradients are held to 5e-3 (measured 1e-3 / 2-3e-3: see
@@ -808,7 +817,11 @@ def test_bf16_storage_decoder_vs_oracle(dev, kind, ragged, pooled):
                 loss, _, _ = R.caption_loss(out[0], out[1], out[2], alphas, 1.0)
                 loss.backward()
                 return out[0], alphas, loss, x2.grad, mm
-        SF.set_option("decoder_bf16", 1)
+        # mode 2 ("mfma"): the activation rows of the per-step products (h, z, the mixed factors and their gradients) are
+        # rounded to bf16 as well and multiplied on the bf16 matrix instruction -- both operands bf16, the usual mixed-
+        # precision contract; same stated tolerance, 1.5x the allowance on the mask-downstream tensors
+        SF.set_option("decoder_bf16", mode)
+        scale = 1.0 if mode == 1 else 1.5       # measured: the same 1.5e-3 / 2-3e-3 as the storage mode, 5.8e-2 on d decoder_att.weight
         for p in m.parameters():
             p.grad = None
         hip = run()
@@ -817,11 +830,11 @@ def test_bf16_storage_decoder_vs_oracle(dev, kind, ragged, pooled):
         # pre-activation closer to zero than that -- far more of them than the fp32 rounding flips (2e-3 there) -- and
         # d decoder_att.weight is the most cancellation-heavy of the four.  The test below holds those four to the
         # 5e-3 of the others with an unambiguous mask.
-        floors = {k: 6e-2 for k in ("attention.encoder_att.weight", "attention.encoder_att.bias",
-                                    "attention.decoder_att.weight", "attention.decoder_att.bias")}
-        floors["attention.full_att.weight"] = 2e-2      # sum of de * relu(att1 + att2): the same mask, and att1 itself
-        _compare(kind, m, hip, r64, floors, "bf16-storage decode step, %s ragged=%s pooled=%s" % (kind, ragged, pooled),
-                 tol_out=5e-3, tol_grad=5e-3)
+        floors = {k: 6e-2 * scale for k in ("attention.encoder_att.weight", "attention.encoder_att.bias",
+                                            "attention.decoder_att.weight", "attention.decoder_att.bias")}
+        floors["attention.full_att.weight"] = 2e-2 * scale      # sum of de * relu(att1 + att2): the same mask, and att1 itself
+        _compare(kind, m, hip, r64, floors, "bf16 decode step (%s), %s ragged=%s pooled=%s"
+                 % ("storage" if mode == 1 else "bf16 MFMA", kind, ragged, pooled), tol_out=5e-3, tol_grad=5e-3)
         bf_preds = hip[0].detach().clone()
         SF.set_option("decoder_bf16", 0)
         for p in m.parameters():

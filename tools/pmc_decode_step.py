@@ -40,7 +40,7 @@ def fetch_multiplier(name):
     weights on average + the re-read 32-row activation tile), i.e. those requests are tallied at their true 64 B."""
     if "skinny_kernel<" in name:
         args = name.split("skinny_kernel<", 1)[1].split(">", 1)[0].replace(" ", "").split(",")
-        if len(args) >= 3 and args[2] == "true":
+        if len(args) >= 3 and args[2] == "true":      # WBF (with or without the bf16 matrix instruction): 2-byte weight loads
             return 1.0
     return 2.0
 
