@@ -25,7 +25,7 @@ extern int g_fuse_attn;
 extern int g_chains;
 extern int g_attn_depth;
 extern int g_attn_handoff, g_handoff_check, g_dec_bf16;
-extern int g_gemm_target, g_gemm_kmin, g_gemm_kmin_small, g_gemm_gate, g_use_cgemm, g_cgemm_target, g_cgemm_kmin, g_cgemm_vec, g_cgemm_mi, g_cgemm_stagger, g_cgemm_w41, g_bn_gfirst;
+extern int g_gemm_target, g_gemm_kmin, g_gemm_kmin_small, g_gemm_gate, g_use_cgemm, g_cgemm_target, g_cgemm_kmin, g_cgemm_vec, g_cgemm_mi, g_cgemm_stagger, g_cgemm_w41, g_bn_gfirst, g_skinny_tail;
 int profile_collect(double* out);
 int seq_workspace(const scnattn_dims* d, const scnattn_pool* pool, size_t* saved_bytes, size_t* scratch_bytes);
 int seq_fwd(hipStream_t st, const scnattn_dims* d, const scnattn_params* w, const float* enc, const float* tags,
@@ -71,6 +71,7 @@ int scnattn_set_option(const char* name, int value) {
     if (name && std::strcmp(name, "use_cgemm") == 0) { g_use_cgemm = value != 0; return 0; }
     if (name && std::strcmp(name, "cgemm_vec") == 0) { g_cgemm_vec = value != 0; return 0; }
     if (name && std::strcmp(name, "cgemm_mi") == 0 && value >= 0 && value <= 2) { g_cgemm_mi = value; return 0; }
+    if (name && std::strcmp(name, "skinny_tail") == 0) { g_skinny_tail = value != 0; return 0; }
     if (name && std::strcmp(name, "bn_gfirst") == 0) { g_bn_gfirst = value != 0; return 0; }
     if (name && std::strcmp(name, "cgemm_w41") == 0) { g_cgemm_w41 = value != 0; return 0; }
     if (name && std::strcmp(name, "cgemm_stagger") == 0 && value >= 0 && value <= 4096) { g_cgemm_stagger = value; return 0; }
