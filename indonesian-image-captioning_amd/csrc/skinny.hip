@@ -88,13 +88,6 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
             f32x4 xv[NB / 2][2];
 #pragma unroll
             for (int j = 0; j < NB / 2; ++j) {
-                const unsigned k = (unsigned)(kw0 + 16 * j + 8 * kk);
-#pragma unroll
-                for (int c = 0; c < 8; ++c)
-                    wr16[j][c] = __builtin_amdgcn_raw_buffer_load_b16(wr, nok ? (k + c) * ldw4 + wcol : OOB_OFF, 0, 0);
-            }
-#pragma unroll
-            for (int j = 0; j < NB / 2; ++j) {
                 const int k = kw0 + 16 * j + 8 * kk;
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
@@ -107,6 +100,14 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
                             xv[j][q][c] = buf_load(xr, (rok && kq + c < kend) ? xrow + (unsigned)(kq + c) * 4u : OOB_OFF);
                     }
                 }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NB / 2; ++j) {
+                const unsigned k = (unsigned)(kw0 + 16 * j + 8 * kk);
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    wr16[j][c] = __builtin_amdgcn_raw_buffer_load_b16(wr, nok ? (k + c) * ldw4 + wcol : OOB_OFF, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -124,16 +125,11 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
     for (int c0 = 0; c0 < per; c0 += 8 * NB) {         // per is a multiple of 8*NB (host guarantees it)
         const int kw0 = kbeg + wave * per + c0;        // first k of this wave's chunk
         // every load of the chunk is issued before the first MFMA
+        // The activation fragments go FIRST: loads retire in order, so with the (small, L2-resident) X loads at the head of
+        // the queue the k-th group of matrix instructions only waits for the k-th group of weight loads
+        // (s_waitcnt vmcnt(4 * (NB - 1 - k))) and the ~1 us matrix chain runs under the arrival of the weight stream;
+        // with them at the tail the first instruction waited for EVERY weight load (vmcnt(NB - 1)).
         float xf[NB][4], wf[NB][4];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const unsigned k = (unsigned)(kw0 + 8 * j + 4 * kk);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const unsigned off = nok ? (k + c) * ldw4 + wcol : OOB_OFF;
-                wf[j][c] = WBF ? bf16_to_f32(__builtin_amdgcn_raw_buffer_load_b16(wr, off, 0, 0)) : buf_load(wr, off);
-            }
-        }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int k = kw0 + 8 * j + 4 * kk;
@@ -145,6 +141,16 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     xf[j][c] = buf_load(xr, (rok && k + c < kend) ? xrow + (unsigned)(k + c) * 4u : OOB_OFF);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const unsigned k = (unsigned)(kw0 + 8 * j + 4 * kk);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const unsigned off = nok ? (k + c) * ldw4 + wcol : OOB_OFF;
+                wf[j][c] = WBF ? bf16_to_f32(__builtin_amdgcn_raw_buffer_load_b16(wr, off, 0, 0)) : buf_load(wr, off);
             }
         }
         // keep the scheduler from re-interleaving loads with the MFMA chain (it would hold only ~8 loads
