@@ -522,7 +522,7 @@ def main():
                                    "note": ("one launch bracketed by two HIP event records on the launch stream, measured in "
                                             "two extra steps outside the timed region: the bracket adds the processing of "
                                             "its own two markers (~3 us); rocprofv3's duration of this kernel inside the same "
-                                            "step is 7.3 us (profiles/r02_full_step_kernel_stats_final.csv)")
+                                            "step is 7.7 us (profiles/r02_full_step_kernel_stats_final.csv)")
                                    if ctx_per_step < 1.5 else
                                    "with 2 chains the two half-batch launches overlap other kernels of the "
                                    "sibling chain, so the per-launch time is not a standalone figure"},
