@@ -449,9 +449,9 @@ def main():
         }
         if not args.decoder_only and not args.no_fused_conv:
             from scnattn import conv as _conv
-            out["config"]["trunk"] = ("fused Bottleneck: every 1x1 convolution (fwd, dgrad, wgrad) on csrc/cgemm.hip with "
-                                      "BatchNorm prologues/epilogues; 3x3 fwd/dgrad per shape by autotune (SCNATTN_CONV3=%s): "
-                                      % _conv.CONV3) + ", ".join("%s%s=%s" % (k[0], list(k[1:]), v) for k, v in sorted(_conv.conv3_choices().items()))
+            out["config"]["trunk"] = ("stem (7x7 conv + BN + ReLU + max-pool) on csrc/stem.hip; fused Bottleneck: every convolution "
+                                      "(1x1 and 3x3; fwd, dgrad, wgrad) on csrc/cgemm.hip / csrc/conv3.hip with BatchNorm "
+                                      "prologues/epilogues; SCNATTN_CONV3=%s" % _conv.CONV3)
             out["config"]["side_stream"] = "; ".join("weight gradients on a second HIP stream, found concurrent with the main "
                                                      "stream by experiment (%s)" % sd.probe for sd in _conv._sides.values()) or None
         if elapsed_di is not None:

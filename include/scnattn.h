@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SCNATTN_VERSION 106 /* 0.1.6: + bf16 modes of the sequence drivers, scnattn_seq_bwd_streams, scnattn_stream_* */
+#define SCNATTN_VERSION 107 /* 0.1.7: + halo-staged 3x3 weight gradient, strided 3x3 d input, the stem (scnattn_stem_*) */
 
 int scnattn_version(void);
 const char* scnattn_last_error(void);
@@ -328,14 +328,39 @@ int scnattn_conv1x1_wgrad(void* stream, int R, int Cin, int Cout, const float* d
  * kernel: no im2col buffer; the nine taps are a walk over K (forward, d input) or a property of the column tile
  * (d weight); a tap that falls outside the image is a lane whose LDS-DMA offset is out of range, i.e. zeros.
  * x [N*Hi*Wi][Cin], y / dy [N*Ho*Wo][Cout] channels-last maps, w / dw [Cout][3][3][Cin] (a channels-last conv weight).
- * Cin, Cout multiples of 16 (d weight: Cin a multiple of 128); d input needs stride 1.
- * ex may carry epi = 1 (fwd: statistics of y) or epi = 2 (dgrad: ReLU mask from z + BatchNorm-backward sums). */
+ * Cin, Cout multiples of 16.  ex may carry epi = 1 (fwd: statistics of y) or epi = 2 (dgrad: ReLU mask from z +
+ * BatchNorm-backward sums). */
 int scnattn_conv3x3_fwd(void* stream, int N, int Hi, int Wi, int Cin, int Cout, int stride, const float* x,
                         const float* w, float* y, const scnattn_conv_extra* ex, float* ws, long ws_floats);
+/* d input of a stride-1 convolution: the nine taps (flipped) walk K */
 int scnattn_conv3x3_dgrad(void* stream, int N, int Hi, int Wi, int Cin, int Cout, const float* dy, const float* w,
                           float* dx, const scnattn_conv_extra* ex, float* ws, long ws_floats);
+/* d input of a STRIDE-2 convolution (conv2 of layer2.0 / 3.0 / 4.0; Hi, Wi even): ONE launch whose grid.y runs over the
+ * four parity classes (hi & 1, wi & 1) of d-input pixels; a class sees only the taps that reach it (1, 2, 2 or 4 of the
+ * nine), so nothing is multiplied by the zeros a zero-inserted dy would carry.  dy [N*(Hi/2)*(Wi/2)][Cout]. */
+int scnattn_conv3x3_dgrad_strided(void* stream, int N, int Hi, int Wi, int Cin, int Cout, int stride, const float* dy,
+                                  const float* w, float* dx, float* ws, long ws_floats);
+/* d weight.  stride 1, Cin % 32 == 0, Cout % 32 == 0 (every identity Bottleneck of the trunk): the
+ * HALO-STAGED kernel of csrc/conv3.hip -- a wave owns a 32 x 32 block of dw for all nine taps (nine accumulators), walks
+ * output pixels strip by strip and reads each staged activation line at nine shifted LDS addresses, so an activation
+ * byte is staged once instead of nine times; the four waves of a workgroup split K and meet in LDS; k_slices > 0 fixes
+ * the workgroup-level K split (0: policy, ~512 workgroups), whose slabs (k_slices * |dw| floats in ws) a second launch
+ * sums in slab order.  Otherwise (strided, or k_slices < 0): the gathered [K][M] x [K][N] form on scnattn_cgemm's
+ * kernel (needs Cin % 128 == 0). */
 int scnattn_conv3x3_wgrad(void* stream, int N, int Hi, int Wi, int Cin, int Cout, int stride, const float* dy,
-                          const float* x, float* dw, float* ws, long ws_floats);
+                          const float* x, float* dw, float* ws, long ws_floats, int k_slices);
+/* ---- the stem: conv1 7x7 / 2 / pad 3 (3 -> 64) -> BatchNorm -> ReLU -> MaxPool 3x3 / 2 / pad 1 (csrc/stem.hip) ----------
+ * children 0..3 of the trunk behind models/encoders/caption.py:17-22; frozen in every configuration of the reference, so
+ * forward only.  x is the (N,3,H,W) image batch in ANY memory format (element strides sn, sc, sh, sw), w the (64,3,7,7)
+ * weight in any format (wn, wc, wh, ww).  scnattn_stem_conv7 writes z [N*Ho*Wo][64] (Ho = (H-1)/2+1) and, when
+ * stat_partial is given, per-workgroup sums {sum(z - s), sum((z - s)^2)} [scnattn_stem_tiles(N,H,W)][2][64] for
+ * scnattn_bn_finalize (s = stat_shift[c] or 0).  scnattn_stem_bn_relu_maxpool: out [N*Hp*Wp][C] = max over the 3x3 window
+ * of relu(z*scale[c] + shift[c]) with ss [C][2] = {scale, shift} (scnattn_bn_finalize's ss_out), Hp = (Hz-1)/2+1. */
+int scnattn_stem_tiles(int N, int H, int W);
+int scnattn_stem_conv7(void* stream, int N, int H, int W, const float* x, long sn, long sc, long sh, long sw,
+                       const float* w, long wn, long wc, long wh, long ww, float* z, float* stat_partial,
+                       const float* stat_shift);
+int scnattn_stem_bn_relu_maxpool(void* stream, int N, int Hz, int Wz, int C, const float* z, const float* ss, float* out);
 /* ---- whole-block drivers (csrc/bottleneck.cpp): ONE call enqueues every kernel of a Bottleneck's forward pass, ONE its
  * backward pass -- torchvision's Bottleneck behind models/encoders/caption.py:17-22, out = relu(bn3(conv3(relu(bn2(
  * conv2(relu(bn1(conv1(x)))))))) + identity) with BatchNorm in training mode -- the way scnattn_seq_fwd/bwd do for the

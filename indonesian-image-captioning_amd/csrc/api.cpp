@@ -203,14 +203,40 @@ int scnattn_conv3x3_dgrad(void* stream, int N, int Hi, int Wi, int Cin, int Cout
                  nullptr, 1, 0, 0, 0, ws, ws ? ws_floats : 0, &e);
 }
 
+int scnattn_conv3x3_dgrad_strided(void* stream, int N, int Hi, int Wi, int Cin, int Cout, int stride, const float* dy,
+                                  const float* w, float* dx, float* ws, long ws_floats) {
+    SCN_ARG(N > 0 && Hi > 0 && Wi > 0 && stride == 2 && Hi % 2 == 0 && Wi % 2 == 0, "conv3x3_dgrad_strided: stride 2, even map");
+    ConvExtra e;
+    const int Ho = Hi / 2, Wo = Wi / 2;
+    // one launch, four parity classes of d-input pixels (grid.y), each a product over the taps that reach it
+    e.c3 = 4; e.c3c = Cout; e.c3_src_rows = (long)N * Ho * Wo; e.Hi = Hi; e.Wi = Wi; e.Ho = Ho; e.Wo = Wo; e.stride = 2;
+    return cgemm(ST(stream), false, false, N * Ho * Wo, Cin, 9 * Cout, 1.f, dy, Cout, w, 9L * Cin, 0.f, dx, Cin, nullptr,
+                 nullptr, 1, 0, 0, 0, ws, ws ? ws_floats : 0, &e);
+}
+
 int scnattn_conv3x3_wgrad(void* stream, int N, int Hi, int Wi, int Cin, int Cout, int stride, const float* dy,
-                          const float* x, float* dw, float* ws, long ws_floats) {
+                          const float* x, float* dw, float* ws, long ws_floats, int k_slices) {
     SCN_ARG(N > 0 && Hi > 0 && Wi > 0 && stride >= 1, "conv3x3_wgrad: geometry");
+    // stride 1: the halo-staged kernel (csrc/conv3.hip); strided (layerN.0) or odd widths: the gather form of cgemm
+    if (stride == 1 && k_slices >= 0 && conv3x3_wgrad_halo_ok(N, Hi, Wi, Cin, Cout, dy, x, dw))
+        return conv3x3_wgrad_halo(ST(stream), N, Hi, Wi, Cin, Cout, dy, x, dw, ws, ws ? ws_floats : 0, k_slices);
     ConvExtra e;
     const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
     e.c3 = 3; e.c3c = Cin; e.c3_src_rows = (long)N * Hi * Wi; e.Hi = Hi; e.Wi = Wi; e.Ho = Ho; e.Wo = Wo; e.stride = stride;
     return cgemm(ST(stream), true, false, Cout, 9 * Cin, N * Ho * Wo, 1.f, dy, Cout, x, Cin, 0.f, dw, 9L * Cin, nullptr,
                  nullptr, 1, 0, 0, 0, ws, ws ? ws_floats : 0, &e);
+}
+
+int scnattn_stem_tiles(int N, int H, int W) { return stem_tiles(N, H, W); }
+
+int scnattn_stem_conv7(void* stream, int N, int H, int W, const float* x, long sn, long sc, long sh, long sw,
+                       const float* w, long wn, long wc, long wh, long ww, float* z, float* stat_partial,
+                       const float* stat_shift) {
+    return stem_conv7(ST(stream), N, H, W, x, sn, sc, sh, sw, w, wn, wc, wh, ww, z, stat_partial, stat_shift);
+}
+
+int scnattn_stem_bn_relu_maxpool(void* stream, int N, int Hz, int Wz, int C, const float* z, const float* ss, float* out) {
+    return stem_bn_relu_maxpool(ST(stream), N, Hz, Wz, C, z, ss, out);
 }
 
 int scnattn_bn_finalize(void* stream, long R, int C, int nchunk, const float* partial, const float* shift, float eps,

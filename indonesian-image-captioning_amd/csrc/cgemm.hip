@@ -63,6 +63,7 @@ struct CArgs {
     int gHi, gWi, gHo, gWo, gs;   // row gather (strided 1x1 convolution); gs == 0: none.  3x3: source / destination maps
     int c3c;                      // 3x3 modes: channels per tap of the gathered operand (Cin forward / wgrad, Cout dgrad)
     long src_rows;                // 3x3 modes: rows of the gathered map (N * gHi * gWi)
+    int dHi, dWi;                 // mode 4: extent of the d-input map the rows are scattered into
     const float* pro_ss;          // interleaved {scale, shift} per channel: PRO 1 per k (A), PRO 2 per n (B)
     float* stat_partial; const float* stat_shift;       // [cdiv(M, 64)][2][N]
     const float* ez; const float* emean; const float* einvstd; const float* egamma; const float* ebeta;  // mask pass
@@ -110,6 +111,11 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 //     1 forward  Y[(n,ho,wo)][co] = sum_{tap,ci} X[(n, ho*s+dh-1, wo*s+dw-1)][ci] * W[co][tap][ci]     (A rows gathered per tap)
 //     2 dgrad    dX[(n,hi,wi)][ci] = sum_{tap,co} dY[(n, hi-dh+1, wi-dw+1)][co] * W[co][tap][ci]       (stride 1; B rows (tap,co))
 //     3 wgrad    dW[co][tap][ci]  = sum_r dY[r][co] * X[(n, ho*s+dh-1, wo*s+dw-1)][ci]                 (B k-rows gathered, tap per n-tile)
+//     4 dgrad of a STRIDE-2 convolution, one parity class (ph, pw) = (hi & 1, wi & 1) per blockIdx.y: only the taps with
+//       hi + 1 - dh even reach an output row, so the classes see 1 / 2 / 2 / 4 of the nine taps (K = taps * Cout) -- no
+//       multiplication by the zeros a zero-inserted dY would carry.  Class row m = (n, ho', wo') of the Ho x Wo grid;
+//       it gathers dY[(n, ho' + oh, wo' + ow)] (oh = 1 for the tap dh = 0 of an odd row, else 0) and is stored at d-input
+//       row (n, 2 ho' + ph, 2 wo' + pw).
 template <int MI, bool A_MC, bool B_MC, int PRO, int EPI, bool GATHER, bool VEC, int C3 = 0>
 __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
     __shared__ __attribute__((aligned(16))) float lds[NSTAGE * STAGE_F];
@@ -148,18 +154,19 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
     }
     const int tm = bid / g.nt, tn = bid - tm * g.nt;
     const int m0 = tm * TM, n0 = tn * (W41 ? 64 : TN);      // 4 x 1 layout: 64-column tiles
-    const int zb = blockIdx.y / g.S, sp = blockIdx.y - zb * g.S;
+    const int cls = C3 == 4 ? 3 - (int)blockIdx.y : 0, ph = cls >> 1, pw = cls & 1, ntw = 1 + pw;   // mode 4: parity class, the 4-tap one dispatched first
+    const int zb = C3 == 4 ? 0 : blockIdx.y / g.S, sp = C3 == 4 ? 0 : blockIdx.y - zb * g.S;
     const float* A = g.A + (long)zb * g.sA;
     const float* B = g.B + (long)zb * g.sB;
     float* C = g.C + (long)zb * g.sC;
-    const int kbeg = sp * g.kper, Kend = min(g.K, kbeg + g.kper);
+    const int kbeg = sp * g.kper, Kend = C3 == 4 ? (1 + ph) * ntw * g.c3c : min(g.K, kbeg + g.kper);
     const int nk = (Kend - kbeg + TK - 1) / TK;
 
-    const long a_elems = (C3 == 1 || C3 == 2) ? g.src_rows * g.lda
+    const long a_elems = (C3 == 1 || C3 == 2 || C3 == 4) ? g.src_rows * g.lda
                          : A_MC ? ((long)(g.K - 1) * g.lda + g.M)
                                 : (GATHER ? (gather_row(g, g.M - 1) * g.lda + g.K) : ((long)(g.M - 1) * g.lda + g.K));
     const long b_elems = C3 == 3 ? g.src_rows * g.ldb
-                         : C3 == 2 ? (long)(g.K / 9) * g.ldb
+                         : (C3 == 2 || C3 == 4) ? (long)(g.K / 9) * g.ldb
                          : B_MC ? ((GATHER && A_MC ? gather_row(g, g.K - 1) : (long)(g.K - 1)) * g.ldb + g.N)
                                 : ((long)(g.N - 1) * g.ldb + g.K);
     const __amdgpu_buffer_rsrc_t ars = make_rsrc(A, (unsigned)(a_elems * 4));
@@ -175,15 +182,15 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
 #pragma unroll
     for (int c = 0; c < ACH; ++c) {
         const int chunk = wave * ACH + c;
-        if (C3 == 1 || C3 == 2) {
+        if (C3 == 1 || C3 == 2 || C3 == 4) {
             const int row = chunk * 16 + (lane >> 2), gsrc = (lane & 3) ^ ((row >> 2) & 3);
             const int grow = m0 + row;
             a_ok[c] = grow < g.M;
             const int r = a_ok[c] ? grow : 0, hw = g.gHo * g.gWo;
             const int n = r / hw, rem = r - n * hw, hd = rem / g.gWo, wd = rem - hd * g.gWo;
             a_nb[c] = n * g.gHi * g.gWi;
-            a_h0[c] = hd * g.gs - 1;
-            a_w0[c] = wd * g.gs - 1;
+            a_h0[c] = C3 == 4 ? hd : hd * g.gs - 1;
+            a_w0[c] = C3 == 4 ? wd : wd * g.gs - 1;
             a_off[c] = (unsigned)(gsrc * 16);
         } else if (!A_MC) {
             const int row = chunk * 16 + (lane >> 2), gsrc = (lane & 3) ^ ((row >> 2) & 3);
@@ -224,7 +231,12 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
         for (int c = 0; c < ACH; ++c) {
             const int chunk = wave * ACH + c;
             unsigned va;
-            if (C3 == 1 || C3 == 2) {       // k-step -> one tap (c3c % 16 == 0), channels c0 .. c0+15 of it
+            if (C3 == 4) {                  // class tap t = (th, tw): source pixel (ho' + oh, wo' + ow)
+                const int t = k0 / g.c3c, c0 = k0 - t * g.c3c, th = t / ntw, tw = t - th * ntw;
+                const int hi = a_h0[c] + ((ph && th == 0) ? 1 : 0), wi = a_w0[c] + ((pw && tw == 0) ? 1 : 0);
+                const bool ok = a_ok[c] && k0 < Kend && hi < g.gHi && wi < g.gWi;
+                va = ok ? (unsigned)(((long)(a_nb[c] + hi * g.gWi + wi) * g.lda + c0) * 4) + a_off[c] : OOB_OFF;
+            } else if (C3 == 1 || C3 == 2) {       // k-step -> one tap (c3c % 16 == 0), channels c0 .. c0+15 of it
                 const int tap = k0 / g.c3c, c0 = k0 - tap * g.c3c;
                 int dh = tap / 3, dw = tap - 3 * dh;
                 if (C3 == 2) { dh = 2 - dh; dw = 2 - dw; }
@@ -249,7 +261,11 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
                 vb = (b_ok[c] && kk < Kend) ? b_off[c] + (unsigned)k0 * 4u : OOB_OFF;
             } else {
                 const int kr = k0 + chunk * 2 + (lane >> 5);
-                if (C3 == 2) {            // B row k = (tap, co) of W[co][tap][ci]: co*ldb + tap*Cin + ci
+                if (C3 == 4) {            // B row k = (class tap t, co): the weight tap is (dh, dw) = (ph ? 2*th : 1, pw ? 2*tw : 1)
+                    const int t = k0 / g.c3c, co = kr - t * g.c3c, th = t / ntw, tw = t - th * ntw;
+                    const int tap = (ph ? 2 * th : 1) * 3 + (pw ? 2 * tw : 1);
+                    vb = (b_ok[c] && kr < Kend) ? (unsigned)(((long)co * g.ldb + (long)tap * g.N + n0 + 4 * (lane & 31)) * 4) : OOB_OFF;
+                } else if (C3 == 2) {            // B row k = (tap, co) of W[co][tap][ci]: co*ldb + tap*Cin + ci
                     const int tap = k0 / g.c3c, co = kr - tap * g.c3c;
                     vb = (b_ok[c] && kr < Kend) ? (unsigned)(((long)co * g.ldb + (long)tap * g.N + n0 + 4 * (lane & 31)) * 4) : OOB_OFF;
                 } else if (C3 == 3) {     // B k-row r = output pixel; the column tile fixes the tap (c3c % 128 == 0)
@@ -399,8 +415,16 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
     const bool cok = ncol < g.N;
     const long c_ld = g.S > 1 ? (long)g.N : g.ldc;
     float* const c_base = g.S > 1 ? g.ws + ((long)blockIdx.y * g.M) * g.N : C;
-    const __amdgpu_buffer_rsrc_t ors = make_rsrc(c_base, VEC ? (unsigned)(((long)(g.M - 1) * c_ld + g.N) * 4) : 0u);
-    auto row_off = [&](int m) -> unsigned { return (m < g.M && cok) ? (unsigned)(((long)m * c_ld + ncol) * 4) + opq : OOB_OFF; };
+    const __amdgpu_buffer_rsrc_t ors = make_rsrc(c_base, VEC ? (unsigned)(((long)((C3 == 4 ? 4 * g.M : g.M) - 1) * c_ld + g.N) * 4) : 0u);
+    auto row_off = [&](int m) -> unsigned {
+        if (!(m < g.M && cok)) return OOB_OFF;
+        long rr = m;
+        if (C3 == 4) {      // class row (n, ho', wo') -> d-input row (n, 2 ho' + ph, 2 wo' + pw)
+            const int hw = g.gHo * g.gWo, n = m / hw, rem = m - n * hw, hd = rem / g.gWo, wd = rem - hd * g.gWo;
+            rr = ((long)n * g.dHi + 2 * hd + ph) * g.dWi + 2 * wd + pw;
+        }
+        return (unsigned)((rr * c_ld + ncol) * 4) + opq;
+    };
     // one 32-row block of this wave from the accumulators into the transpose region
     auto dump_half = [&](int i, float add0, float add1) {
 #pragma unroll
@@ -769,6 +793,8 @@ int launch_conv3(hipStream_t st, dim3 grid, const CArgs& g, int c3, int kepi) {
         else           hipLaunchKernelGGL((cgemm_kernel<MI, false, false, 0, 0, false, true, 1>), grid, block, 0, st, g);
     } else if (c3 == 2) {
         hipLaunchKernelGGL((cgemm_kernel<MI, false, true, 0, 0, false, true, 2>), grid, block, 0, st, g);
+    } else if (c3 == 4) {
+        hipLaunchKernelGGL((cgemm_kernel<MI, false, true, 0, 0, false, true, 4>), grid, block, 0, st, g);
     } else {
         hipLaunchKernelGGL((cgemm_kernel<MI, true, true, 0, 0, false, true, 3>), grid, block, 0, st, g);
     }
@@ -808,10 +834,12 @@ int cgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
     const int c3 = ex ? ex->c3 : 0;
     const bool gather = ex && ex->stride > 1 && c3 == 0;
     if (c3) {
-        SCN_ARG(c3 >= 1 && c3 <= 3 && pro == 0 && batch == 1 && beta == 0.f && !bias && !rowmask, "cgemm: 3x3 mode takes a plain product");
+        SCN_ARG(c3 >= 1 && c3 <= 4 && pro == 0 && batch == 1 && beta == 0.f && !bias && !rowmask, "cgemm: 3x3 mode takes a plain product");
         SCN_ARG(ex->Hi > 0 && ex->Wi > 0 && ex->Ho > 0 && ex->Wo > 0 && ex->stride >= 1 && ex->c3c > 0 && ex->c3_src_rows > 0, "cgemm: 3x3 geometry");
         SCN_ARG((c3 == 1 && !tA && tB && K == 9 * ex->c3c && ex->c3c % 16 == 0) ||
                 (c3 == 2 && !tA && !tB && K == 9 * ex->c3c && ex->c3c % 16 == 0 && ex->stride == 1) ||
+                (c3 == 4 && !tA && !tB && K == 9 * ex->c3c && ex->c3c % 16 == 0 && ex->stride == 2 && epi == 0 &&
+                 ex->Hi == 2 * ex->Ho && ex->Wi == 2 * ex->Wo && (long)4 * M * ldc * 4 < 0x7fffffffL) ||
                 (c3 == 3 && tA && !tB && N == 9 * ex->c3c && ex->c3c % 128 == 0), "cgemm: 3x3 mode / layout / channel multiple");
         SCN_ARG(ex->c3_src_rows * (c3 == 3 ? ldb : lda) * 4 < 0x7fffffffL, "cgemm: 3x3 source map exceeds the descriptor range");
     }
@@ -826,7 +854,10 @@ int cgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
     SCN_ARG(epi == 0 || vec, "cgemm: the statistics epilogues need N % 4 == 0, ldc % 4 == 0 and a 16-byte aligned C");
     // row tile: 64 rows when the 128-row grid alone cannot give every CU a workgroup but the 64-row grid can come closer
     int mi = 2;
-    if ((long)cdiv(M, 128) * cdiv(N, TN) * batch < 256 && M > 64 && c3 != 1 && c3 != 2) mi = 1;
+    if ((long)cdiv(M, 128) * cdiv(N, TN) * batch < 256 && M > 64 && c3 != 1 && c3 != 2 && c3 != 4) mi = 1;
+    // stride-2 d input: the four classes carry 1 / 2 / 2 / 4 taps, so the grid is uneven by construction; 64-row tiles
+    // (twice the workgroups, all resident at once) let the dispatcher even it out when the 128-row grid is small
+    if (c3 == 4 && (long)cdiv(M, 128) * cdiv(N, TN) * 4 < 768) mi = 1;
     if (N <= 64 && M >= 128 && g_cgemm_w41 && c3 != 3) mi = 4;     // 128 x 64 tiles, waves 4 x 1 (layer1's 64-channel maps)
     if (g_cgemm_mi == 1 || g_cgemm_mi == 2) mi = g_cgemm_mi;
     if (ex && ex->force_mi > 0) mi = ex->force_mi;
@@ -863,13 +894,14 @@ int cgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
         while (S > 1 && (long)S * batch * M * N > ws_floats) --S;
         if (S < 1) S = 1;
     }
+    if (c3 == 4) S = 1;       // the four parity classes ride on grid.y; their K (1, 2, 2, 4 taps) is never split
     if ((c3 == 1 || c3 == 2) && ws) {   // deep K (9 taps): 128-row tiles, up to 4 K-slices to reach ~512 workgroups (measured)
         S = (int)(512 / (tiles > 0 ? tiles : 1));
         if (S > 4) S = 4;
         if (S < 1) S = 1;
         while (S > 1 && (long)S * M * N > ws_floats) --S;
     }
-    if (ex && ex->force_split > 0) {
+    if (ex && ex->force_split > 0 && c3 != 4) {
         S = ex->force_split;
         SCN_ARG(S == 1 || (ws && (long)S * batch * M * N <= ws_floats && S <= CG_MAX_SPLIT), "cgemm: forced split does not fit");
     }
@@ -884,11 +916,12 @@ int cgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
     if (ex) {
         g.gHi = ex->Hi; g.gWi = ex->Wi; g.gHo = ex->Ho; g.gWo = ex->Wo; g.gs = (gather || c3) ? ex->stride : 0;
         g.c3c = ex->c3c; g.src_rows = ex->c3_src_rows;
+        if (c3 == 4) { g.gHi = ex->Ho; g.gWi = ex->Wo; g.dHi = ex->Hi; g.dWi = ex->Wi; }   // gathered map = dY (Ho x Wo)
         g.pro_ss = ex->pro_ss;
         g.stat_partial = ex->stat_partial; g.stat_shift = ex->stat_shift;
         g.ez = ex->ez; g.emean = ex->emean; g.einvstd = ex->einvstd; g.egamma = ex->egamma; g.ebeta = ex->ebeta; g.ldz = ex->ldz;
     }
-    dim3 grid(mt * nt, batch * S), block(256);
+    dim3 grid(mt * nt, c3 == 4 ? 4 : batch * S), block(256);
     // in-kernel: plain or statistics; the mask pass (epi 2) and every epilogue of a split product run in the second launch
     const int kepi = (S > 1 || epi == 2) ? 0 : epi;
     if (c3) {
@@ -916,5 +949,17 @@ int cgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
 }
 
 int cgemm_row_tiles(int M) { return cdiv(M, SROWS); }
+
+// C[M][N] (leading dimension ldc) = sum of S slabs [S][M][N] in slab order: the split-K reducer on its own, for kernels
+// outside this file that write the same slab layout (csrc/conv3.hip).
+int cgemm_reduce(hipStream_t st, const float* ws, int S, int M, int N, float* C, long ldc) {
+    SCN_ARG(ws && C && S >= 1 && M > 0 && N > 0 && N % 4 == 0 && ldc % 4 == 0 && aligned16(ws) && aligned16(C),
+            "cgemm_reduce: arguments");
+    CArgs g{};
+    g.ws = const_cast<float*>(ws); g.C = C; g.M = M; g.N = N; g.S = S; g.ldc = ldc;
+    hipLaunchKernelGGL(creduce_kernel<true>, dim3(cdiv((long)M * N / 4, 256), 1), dim3(256), 0, st, g);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
 
 }  // namespace scn

@@ -31,7 +31,7 @@ struct ConvExtra {
     int stride = 1, Hi = 0, Wi = 0, Ho = 0, Wo = 0;   // stride > 1: rows of the activation operand are gathered
     int force_split = 0;      // tests / tuning: > 0 forces the split-K factor
     int force_mi = 0;         // tests / tuning: 1 / 2 forces the 64- / 128-row tile
-    int c3 = 0;               // 3x3 convolution as an implicit GEMM: 1 forward, 2 dgrad (stride 1), 3 wgrad
+    int c3 = 0;               // 3x3 convolution as an implicit GEMM: 1 forward, 2 dgrad (stride 1), 3 wgrad, 4 dgrad (stride 2)
     int c3c = 0;              // channels per tap of the gathered operand
     long c3_src_rows = 0;     // rows of the gathered map
 };
@@ -41,6 +41,18 @@ int cgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
           long ldb, float beta, float* C, long ldc, const float* bias, const float* rowmask, int batch, long sA, long sB,
           long sC, float* ws, long ws_floats, const ConvExtra* ex);
 int cgemm_row_tiles(int M);
+int cgemm_reduce(hipStream_t st, const float* ws, int S, int M, int N, float* C, long ldc);
+
+// ---- conv3.hip: 3x3 weight gradient (stride 1) with the activation halo staged once per strip ---------------------
+bool conv3x3_wgrad_halo_ok(int N, int H, int W, int C, int Co, const float* dy, const float* x, const float* dw);
+int conv3x3_wgrad_halo(hipStream_t st, int N, int H, int W, int C, int Co, const float* dy, const float* x, float* dw,
+                       float* ws, long ws_floats, int force_split);
+
+// ---- stem.hip: conv 7x7 / 2 (+ statistics) and BatchNorm + ReLU + MaxPool 3x3 / 2 of the trunk's stem -----------------
+int stem_tiles(int N, int H, int W);
+int stem_conv7(hipStream_t st, int N, int H, int W, const float* x, long sn, long sc, long sh, long sw, const float* w,
+               long wn, long wc, long wh, long ww, float* z, float* partial, const float* stat_shift);
+int stem_bn_relu_maxpool(hipStream_t st, int N, int Hz, int Wz, int C, const float* z, const float* ss, float* out);
 
 // ---- skinny.hip ------------------------------------------------------------------------------
 int skinny_pick_ksplit(int rows, int N, int K, int groups);

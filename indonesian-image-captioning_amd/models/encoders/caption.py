@@ -10,6 +10,7 @@ from torch import nn
 
 from scnattn import functional as SF
 from scnattn.resnet import resnet152_trunk, configure_miopen, manage_bn_counters
+from scnattn.stem import run_trunk, usable as stem_usable
 
 configure_miopen()
 
@@ -32,7 +33,7 @@ class EncoderCaption(nn.Module):
         tensor carries the un-pooled trunk map as `_scn_prepool` so that this build's attention decoders can
         work on its 8x8 source pixels (models/decoders/_common.py::attached_prepool); `pooled=False` returns
         that (B, h, w, 2048) map itself and skips the pooling."""
-        if self.channels_last and images.is_cuda:
+        if self.channels_last and images.is_cuda and not stem_usable(self.resnet, images):      # the fused stem reads any strides
             images = images.contiguous(memory_format=torch.channels_last)
         if images.is_cuda and self.training:
             flat = getattr(self, "_bn_counters", None)
@@ -40,7 +41,7 @@ class EncoderCaption(nn.Module):
                 self._bn_counters = flat = manage_bn_counters(self.resnet)
             if flat is not None:
                 flat.add_(1)     # all BatchNorm num_batches_tracked counters, one launch
-        out = self.resnet(images)
+        out = run_trunk(self.resnet, images)      # stem on csrc/stem.hip, Bottlenecks on scnattn/conv.py
         pre = out.permute(0, 2, 3, 1)             # a contiguous (B, h, w, C) view when the trunk is channels-last
         if not pooled:
             return pre

@@ -10,6 +10,7 @@ from torch import nn
 
 from scnattn import functional as SF
 from scnattn.resnet import resnet152_trunk, configure_miopen, manage_bn_counters
+from scnattn.stem import run_trunk, usable as stem_usable
 
 configure_miopen()
 
@@ -26,7 +27,7 @@ class EncoderTagger(nn.Module):
         self.fine_tune()
 
     def forward(self, images):
-        if self.channels_last and images.is_cuda:
+        if self.channels_last and images.is_cuda and not stem_usable(self.resnet, images):      # the fused stem reads any strides
             images = images.contiguous(memory_format=torch.channels_last)
         if images.is_cuda and self.training:
             flat = getattr(self, "_bn_counters", None)
@@ -34,7 +35,7 @@ class EncoderTagger(nn.Module):
                 self._bn_counters = flat = manage_bn_counters(self.resnet)
             if flat is not None:
                 flat.add_(1)
-        out = self.resnet(images)
+        out = run_trunk(self.resnet, images)      # stem on csrc/stem.hip, Bottlenecks on scnattn/conv.py
         out = out.reshape(out.size(0), -1)
         out = self.dropout(out)
         out = SF.linear(out, self.linear.weight, self.linear.bias)

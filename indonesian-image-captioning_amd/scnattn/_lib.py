@@ -86,7 +86,11 @@ _SIGS = {
     "scnattn_conv1x1_wgrad": ([vp, i32, i32, i32, vp, vp, vp, C.POINTER(ConvExtra), vp, i64], i32),
     "scnattn_conv3x3_fwd": ([vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, C.POINTER(ConvExtra), vp, i64], i32),
     "scnattn_conv3x3_dgrad": ([vp, i32, i32, i32, i32, i32, vp, vp, vp, C.POINTER(ConvExtra), vp, i64], i32),
-    "scnattn_conv3x3_wgrad": ([vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i64], i32),
+    "scnattn_conv3x3_wgrad": ([vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i64, i32], i32),
+    "scnattn_conv3x3_dgrad_strided": ([vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i64], i32),
+    "scnattn_stem_tiles": ([i32, i32, i32], i32),
+    "scnattn_stem_conv7": ([vp, i32, i32, i32, vp, i64, i64, i64, i64, vp, i64, i64, i64, i64, vp, vp, vp], i32),
+    "scnattn_stem_bn_relu_maxpool": ([vp, i32, i32, i32, i32, vp, vp, vp], i32),
     "scnattn_block_sizes": ([C.POINTER(Block), C.POINTER(sz), C.POINTER(sz), C.POINTER(C.c_long)], i32),
     "scnattn_block_fwd": ([vp, C.POINTER(Block), vp, vp, vp, vp, i64, vp, vp], i32),
     "scnattn_block_bwd": ([vp, vp, C.POINTER(Block), vp, vp, vp, vp, vp, vp, C.POINTER(BlockGrads), vp, vp, i64, vp, vp, i32], i32),

@@ -3,23 +3,24 @@
 torchvision's Bottleneck behind the reference's encoder (models/encoders/caption.py:17-22) is
     out = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) + identity),   identity = x | bn_d(conv_d(x))
 with conv1 / conv3 / conv_d 1x1 and conv2 3x3.  On channels-last maps a 1x1 convolution is the GEMM
-[R = N*H*W, Cin] x [Cin, Cout]; this module runs every 1x1 convolution -- forward, d input, d weight -- on the
-hand-written LDS-DMA pipelined MFMA kernel of csrc/cgemm.hip and lets the BatchNorm work ride on it:
+[R = N*H*W, Cin] x [Cin, Cout] and a 3x3 one an implicit GEMM; every convolution of the block -- forward, d input,
+d weight -- runs on the hand-written kernels of csrc/cgemm.hip / csrc/conv3.hip, and the BatchNorm work rides on them:
 
   forward   conv1  + statistics epilogue (sum, sum^2 of z1 per channel)      -> no bn1 statistics pass
-            bn1 apply + relu -> a1 (materialised: the 3x3 conv2 is MIOpen's and needs it)
-            conv2 (MIOpen) -> z2 ; bn2 statistics pass (also writes the folded scale/shift)
+            bn1 apply + relu -> a1 (materialised: the 3x3's zero padding must be zeros of a1, not of z1)
+            conv2 3x3 (implicit GEMM, strided for layerN.0) + statistics epilogue for bn2
             conv3 with the bn2+relu PROLOGUE on its input operand (a2 is never written or read)
                   + statistics epilogue for bn3                                 -> no bn2 apply, no bn3 statistics pass
             bn3 apply + identity + relu -> out
-  backward  bn3 (two passes, as before) -> dz3, d identity
+  backward  bn3 (two passes) -> dz3, d identity
             conv3 wgrad with the bn2+relu prologue on its activation operand (a2 recomputed on load)
             conv3 dgrad with the MASK epilogue: g2 = d a2 * [a2 > 0] + the two bn2-backward column sums
-                                                                                -> no bn2 reduction pass
-            bn2 element-wise half -> dz2 ; conv2 backward (MIOpen) ; bn1 backward (two passes)
-            conv1 wgrad ; conv1 dgrad ACCUMULATING into d identity (beta = 1)   -> no residual-gradient add kernel
-What stays a separate pass is what a 3x3 MIOpen convolution forces (it needs materialised, normalised inputs).
-The strided 1x1 downsample convolution gathers its input rows inside the kernel.
+            bn2 element-wise half -> dz2
+            conv2 wgrad: the halo-staged kernel (stride 1) / the gathered form (stride 2), on the side stream
+            conv2 dgrad: nine flipped taps over K (stride 1) / four parity classes of d-input pixels (stride 2)
+            bn1 backward (two passes) ; conv1 wgrad ; conv1 dgrad ACCUMULATING into d identity (beta = 1)
+The strided 1x1 downsample convolution gathers its input rows inside the kernel.  No library (MIOpen / rocBLAS) kernel
+runs in a block; `SCNATTN_CONV3=miopen` swaps conv2 back to MIOpen for A/B measurements only.
 
 `Bottleneck.forward` (scnattn/resnet.py) calls `bottleneck()` for fp32 CUDA inputs in training mode; everything else
 (eval mode, bf16 autocast, CPU structure tests) takes the unfused module path."""
@@ -33,9 +34,11 @@ from ._lib import ConvExtra
 
 ENABLED = True          # class-wide switch: tests / A-B runs compare against the unfused path
 SIDE_WGRAD = True       # weight gradients on a second HIP stream (see _Side)
-CONV3 = os.environ.get("SCNATTN_CONV3", "auto")   # conv2 (3x3) forward / d input: "hip" = the implicit-GEMM mode of csrc/cgemm.hip, "miopen", or
-                        # "auto" = time both once per shape on first use and keep the faster (what MIOpen's own find
-                        # step does among its solvers); the 3x3 weight gradient stays on MIOpen (side stream)
+CONV3 = os.environ.get("SCNATTN_CONV3", "hip")     # conv2 (3x3): "hip" = the hand-written kernels (the product path);
+                        # "miopen" = MIOpen for all three directions (A/B measurements; tools/, tests that ask for it)
+if CONV3 not in ("hip", "miopen"):
+    raise RuntimeError("SCNATTN_CONV3 must be 'hip' or 'miopen' (the per-shape stopwatch of round 2 is gone)")
+W3_SLICES = int(os.environ.get("SCNATTN_W3_SLICES", "0"))   # tuning: K slices of the halo-staged 3x3 weight gradient (0: policy)
 
 _bufs = {}
 
@@ -52,61 +55,7 @@ def _buffers(dev):
     return b
 
 
-_c3_choice = {}
-
-
-def _conv3_use_hip(kind, key, run_hip, run_miopen):
-    """-> True when the hand-written 3x3 path is to be used for this (kind, shape).  "auto": both are timed once
-    (3 launches each after one warm-up, HIP events) the first time a shape is seen."""
-    if CONV3 == "hip":
-        return True
-    if CONV3 == "miopen":
-        return False
-    k = (kind,) + key
-    c = _c3_choice.get(k)
-    if c is None:
-        t = []
-        for fn in (run_hip, run_miopen):
-            fn()
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            for _ in range(3):
-                fn()
-            b.record()
-            b.synchronize()
-            t.append(a.elapsed_time(b))
-        c = _c3_choice[k] = t[0] <= t[1] * 1.02
-    return c
-
-
-CONV3_WGRAD = os.environ.get("SCNATTN_CONV3_WGRAD", "miopen")   # 3x3 weight gradient: "miopen" (on the side stream; measured 793 vs 771 images/s) or the implicit-GEMM mode ("hip")
-
-
-def conv3_choices():
-    """{(kind, N, H, W, C[, stride]): "hip" | "miopen"} as decided so far by the per-shape autotune."""
-    return {k: ("hip" if v else "miopen") for k, v in _c3_choice.items()}
-
-
-SIDE_PRIORITY = os.environ.get("SCNATTN_SIDE_PRIORITY", "default")     # "low": lowest stream priority the device offers
-
-
-def _new_stream(dev, low):
-    """PyTorch's stream pool knows two priorities (normal, high); HIP has a third, lower one.  "low": a raw HIP stream of
-    the lowest priority (include/scnattn.h scnattn_stream_create) wrapped as an ExternalStream."""
-    if low:
-        h = _lib.lib()
-        lo, hi = C.c_int(0), C.c_int(0)
-        _chk(h.scnattn_stream_priority_range(C.byref(lo), C.byref(hi)), "scnattn_stream_priority_range")
-        with torch.cuda.device(dev):
-            raw = C.c_void_p()
-            _chk(h.scnattn_stream_create(lo.value, C.byref(raw)), "scnattn_stream_create")
-        st = torch.cuda.ExternalStream(raw.value, device=dev)
-        st._scn_priority = (lo.value, hi.value)
-        return st
-    return torch.cuda.Stream(device=dev)
-
-
-def _concurrent_stream(dev, attempts=8, beside=(), low=None):
+def _concurrent_stream(dev, attempts=8, beside=()):
     """A stream whose kernels really run beside the current stream's.  HIP multiplexes its streams onto a few hardware
     queues (4 by default); two streams that land on the same queue are serialised, and which ones collide depends on
     how many streams the process created before (RCCL's, the allocator's, another module's).  Measured on MI355X: with
@@ -119,7 +68,7 @@ def _concurrent_stream(dev, attempts=8, beside=(), low=None):
     tried = []
     with torch.cuda.device(dev):
         for i in range(attempts):
-            cand = _new_stream(dev, SIDE_PRIORITY == "low" if low is None else low)
+            cand = torch.cuda.Stream(device=dev)
             tried.append(cand)                 # keep it referenced: the pool hands out a different stream next time
             with torch.cuda.stream(cand):
                 probe.add_(1.0)                # code object / allocator warm-up on the candidate
@@ -198,19 +147,33 @@ def _side(dev):
     return sd
 
 
+def _sweep_id():
+    """Id of the autograd sweep this thread is executing (-1 outside one)."""
+    return torch._C._current_graph_task_id()
+
+
 def side_ok(*params):
     """May the gradients of `params` be produced on the side stream?  Only while autograd merely STORES what backward
-    returns for them: a leaf whose .grad is None (AccumulateGrad keeps the tensor; no kernel touches it before the join
-    at the end of the sweep).  A non-leaf's gradient is consumed by the next backward node on the main stream at once,
-    an existing .grad is added to on the main stream at once."""
+    returns for them: a leaf whose .grad is None and that this sweep has not produced a gradient for yet
+    (AccumulateGrad keeps the tensor; no kernel touches it before the join at the end of the sweep).  A non-leaf's
+    gradient is consumed by the next backward node on the main stream at once; an existing .grad -- or a second use of
+    the same weight in one sweep -- is added to on the main stream at once: then everything the side stream still has
+    in flight is joined first and the gradients are produced in line."""
     if not SIDE_WGRAD:
         return False
+    task = _sweep_id()
+    ok = True
     for p in params:
         if p is None:
             continue
-        if not p.is_leaf or p.grad is not None:
-            return False
-    return True
+        if not p.is_leaf or p.grad is not None or (task != -1 and getattr(p, "_scn_sweep", None) == task):
+            ok = False
+    if not ok:
+        for sd in _sides.values():
+            ev = torch.cuda.Event()
+            ev.record(sd.stream)
+            torch.cuda.current_stream(sd.stream.device).wait_event(ev)
+    return ok
 
 
 def join_side_streams():
@@ -284,9 +247,20 @@ def _finalize(h, st, R, Cn, part, bn_mod, training, gamma, beta, want_ss):
 
 def _grad_out(w):
     """Where a weight gradient is written: the parameter's slice of the flat gradient buffer when it has one
-    (scnattn/flat.py; saves the optimizer's gather copy), a fresh tensor otherwise."""
+    (scnattn/flat.py; saves the optimizer's gather copy), a fresh tensor otherwise.
+
+    The flat slice is handed out as a FRESH alias (`detach()`): AccumulateGrad steals a gradient only when nobody else
+    holds the tensor object, and the persistent view is held by the FlatBuffer -- returning that object made autograd
+    clone it on the main stream while the side stream could still be writing it.  And only for the first gradient of a
+    sweep into an empty .grad: a kernel writing into the slice a second time would overwrite what autograd is about to
+    add to (an existing .grad after `FlatBuffer.gather` without `zero_grad`, or a weight used twice in one graph)."""
     gv = getattr(w, "_scn_flat_grad", None)
-    return gv if gv is not None else torch.empty_like(w)
+    task = _sweep_id()
+    first = task == -1 or getattr(w, "_scn_sweep", None) != task
+    w._scn_sweep = task
+    if gv is None or w.grad is not None or not first:
+        return torch.empty_like(w)
+    return gv.detach()
 
 
 def _wt(h, st, w, cout, cin):
@@ -321,29 +295,19 @@ class _BottleneckFn(torch.autograd.Function):
         a1 = torch.empty_like(z1)
         _chk(h.scnattn_bn_apply(st, Rin, p, z1.data_ptr(), None, 0, st1[0].data_ptr(), st1[1].data_ptr(), g1.data_ptr(),
                                 b1.data_ptr(), 1, a1.data_ptr()), "scnattn_bn_apply")
-        # conv2 (3x3): the implicit-GEMM mode of the same kernel with the bn2 statistics epilogue, or MIOpen + a statistics
-        # pass -- whichever is faster for this shape (CONV3)
+        # conv2 (3x3, strided for layerN.0): the implicit-GEMM mode of the same kernel with the bn2 statistics epilogue
         a1_4 = _as4d(a1, N, Hi, Wi)
-        c3ok = p % 16 == 0 and w2.is_contiguous(memory_format=torch.channels_last)
-
-        def hip_fwd():
-            z = torch.empty((Rout, p), device=dev, dtype=torch.float32)
+        if CONV3 == "hip":
+            z2 = torch.empty((Rout, p), device=dev, dtype=torch.float32)
             ex3 = ConvExtra(epi=1, stat_partial=part.data_ptr(), stat_shift=bn2.running_mean.data_ptr())
-            _chk(h.scnattn_conv3x3_fwd(st, N, Hi, Wi, p, p, s, a1.data_ptr(), w2.data_ptr(), z.data_ptr(), C.byref(ex3),
+            _chk(h.scnattn_conv3x3_fwd(st, N, Hi, Wi, p, p, s, a1.data_ptr(), w2.data_ptr(), z2.data_ptr(), C.byref(ex3),
                                        ws.data_ptr(), ws.numel()), "scnattn_conv3x3_fwd")
-            return z
-
-        def miopen_fwd():
+            st2, ss2 = _finalize(h, st, Rout, p, part, bn2, True, g2, b2, True)
+        else:       # A/B only: MIOpen + a statistics pass over z2
             z4 = torch.ops.aten.convolution(a1_4, w2, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1)
             if not z4.is_contiguous(memory_format=torch.channels_last):
                 z4 = z4.contiguous(memory_format=torch.channels_last)
-            return _as2d(z4)
-
-        if c3ok and _conv3_use_hip("fwd", (N, Hi, Wi, p, s), hip_fwd, miopen_fwd):
-            z2 = hip_fwd()
-            st2, ss2 = _finalize(h, st, Rout, p, part, bn2, True, g2, b2, True)
-        else:
-            z2 = miopen_fwd()
+            z2 = _as2d(z4)
             st2 = torch.empty((2, p), device=dev, dtype=torch.float32)
             ss2 = torch.empty((p, 2), device=dev, dtype=torch.float32)
             _chk(h.scnattn_bn_stats_fold(st, Rout, p, z2.data_ptr(), bn2.eps, bn2.momentum, bnpart.data_ptr(),
@@ -425,40 +389,34 @@ class _BottleneckFn(torch.autograd.Function):
         _chk(h.scnattn_bn_bwd_dx(st, Rout, p, g2m.data_ptr(), z2.data_ptr(), st2[0].data_ptr(), st2[1].data_ptr(),
                                  g2.data_ptr(), dgb2[0].data_ptr(), dgb2[1].data_ptr(), dz2.data_ptr()), "scnattn_bn_bwd_dx")
         del g2m
-        # ---- conv2 (MIOpen) -------------------------------------------------------------------------------------
-        dz2_4, a1_4 = _as4d(dz2, N, Ho, Wo), _as4d(a1, N, Hi, Wi)
+        # ---- conv2: weight gradient (side stream) and d input ------------------------------------------------------------
         dw2 = None
-        if need[5]:       # weight gradient: side stream when there is one, the same kernel on the main stream otherwise
-            if CONV3_WGRAD == "hip" and p % 128 == 0 and w2.is_contiguous(memory_format=torch.channels_last):
-                dw2 = torch.empty_like(w2)
+        if CONV3 == "hip":
+            if need[5]:
+                dw2 = _grad_out(w2)
                 sw, wsw = (side.fork(main, dz2, a1, dw2), side.ws) if side else (st, ws)
                 _chk(h.scnattn_conv3x3_wgrad(sw, N, Hi, Wi, p, p, s, dz2.data_ptr(), a1.data_ptr(), dw2.data_ptr(),
-                                             wsw.data_ptr(), wsw.numel()), "scnattn_conv3x3_wgrad")
-            elif side:
-                side.fork(main, dz2, a1)
-                with torch.cuda.stream(side.stream):
-                    _, dw2, _ = torch.ops.aten.convolution_backward(dz2_4, a1_4, w2, None, [s, s], [1, 1], [1, 1], False,
-                                                                    [0, 0], 1, [False, True, False])
+                                             wsw.data_ptr(), wsw.numel(), W3_SLICES), "scnattn_conv3x3_wgrad")
+            da1 = torch.empty((Rin, p), **f32)
+            if s == 1:
+                _chk(h.scnattn_conv3x3_dgrad(st, N, Hi, Wi, p, p, dz2.data_ptr(), w2.data_ptr(), da1.data_ptr(), None,
+                                             ws.data_ptr(), ws.numel()), "scnattn_conv3x3_dgrad")
             else:
-                _, dw2, _ = torch.ops.aten.convolution_backward(dz2_4, a1_4, w2, None, [s, s], [1, 1], [1, 1], False,
-                                                                [0, 0], 1, [False, True, False])
-        c3ok = s == 1 and p % 16 == 0 and w2.is_contiguous(memory_format=torch.channels_last)
-
-        def hip_dgrad():
-            d = torch.empty((Rin, p), **f32)
-            _chk(h.scnattn_conv3x3_dgrad(st, N, Hi, Wi, p, p, dz2.data_ptr(), w2.data_ptr(), d.data_ptr(), None,
-                                         ws.data_ptr(), ws.numel()), "scnattn_conv3x3_dgrad")
-            return _as4d(d, N, Hi, Wi)
-
-        def miopen_dgrad():
-            return torch.ops.aten.convolution_backward(dz2_4, a1_4, w2, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1,
-                                                       [True, False, False])[0]
-
-        da1_4 = hip_dgrad() if (c3ok and _conv3_use_hip("dgrad", (N, Hi, Wi, p), hip_dgrad, miopen_dgrad)) \
-            else miopen_dgrad()
-        if not da1_4.is_contiguous(memory_format=torch.channels_last):
-            da1_4 = da1_4.contiguous(memory_format=torch.channels_last)
-        da1 = _as2d(da1_4)
+                _chk(h.scnattn_conv3x3_dgrad_strided(st, N, Hi, Wi, p, p, s, dz2.data_ptr(), w2.data_ptr(), da1.data_ptr(),
+                                                     ws.data_ptr(), ws.numel()), "scnattn_conv3x3_dgrad_strided")
+        else:       # A/B only: MIOpen
+            dz2_4, a1_4 = _as4d(dz2, N, Ho, Wo), _as4d(a1, N, Hi, Wi)
+            if need[5]:
+                if side:
+                    side.fork(main, dz2, a1)
+                with torch.cuda.stream(side.stream if side else main):
+                    dw2 = torch.ops.aten.convolution_backward(dz2_4, a1_4, w2, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1,
+                                                              [False, True, False])[1]
+            da1_4 = torch.ops.aten.convolution_backward(dz2_4, a1_4, w2, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1,
+                                                        [True, False, False])[0]
+            if not da1_4.is_contiguous(memory_format=torch.channels_last):
+                da1_4 = da1_4.contiguous(memory_format=torch.channels_last)
+            da1 = _as2d(da1_4)
         # ---- bn1 (+ relu, mask recomputed from z1) ----------------------------------------------------------------
         need_dx = need[1]
         dz1 = torch.empty((Rin, p), **f32)
@@ -512,151 +470,6 @@ class _BottleneckFn(torch.autograd.Function):
                 (dgbd[0] if need[13] else None) if dgbd is not None else None)
 
 
-# Identity blocks through the whole-block C drivers (one call forward, one backward): SCNATTN_BLOCK_DRIVER=1.  Measured on
-# one MI355X: the step is GPU-bound either way; the per-call path with its per-shape conv2 autotune is 1.5 % faster on a
-# single GPU (789-800 vs 777-782 images/s) and equal within noise under the data-parallel hooks (--force-dist, one rank:
-# 760 / 770 vs 766 / 769 images/s with the torch / C-ABI RCCL back end).  So the drivers are an entry point for hosts that
-# cannot afford ~40 Python-level calls per block (include/scnattn.h: scnattn_block_*), not the default of this one.
-_drv = os.environ.get("SCNATTN_BLOCK_DRIVER", "0")
-C_DRIVER = None if _drv == "auto" else (_drv != "0")
-
-
-def _use_c_driver():
-    if C_DRIVER is not None:
-        return C_DRIVER
-    import torch.distributed as dist
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-
-_block_sizes = {}
-_scratch_rings = {}
-
-
-def _scratch(dev, nfloats, main):
-    """Backward scratch of the block driver from a ring of three buffers per size.  A fresh torch.empty per call would
-    have to be record_stream()-ed for the side stream, and with the host now far ahead of the GPU the caching allocator
-    could not reuse such blocks in time (it falls back to hipMalloc, which stalls the device).  A ring slot is reused two
-    blocks later; the main stream first waits for the event the side stream recorded when it last used the slot."""
-    key = (dev, nfloats)
-    ring = _scratch_rings.get(key)
-    if ring is None:
-        ring = _scratch_rings[key] = {"i": 0, "slots": [[torch.empty(nfloats, device=dev, dtype=torch.float32), None]
-                                                         for _ in range(3)]}
-    slot = ring["slots"][ring["i"]]
-    ring["i"] = (ring["i"] + 1) % 3
-    if slot[1] is not None:
-        main.wait_event(slot[1])
-    return slot
-
-
-def _block_struct(mod, N, Hi, Wi):
-    from ._lib import Block
-    bn1, bn2, bn3 = mod.bn1, mod.bn2, mod.bn3
-    p, cin = mod.conv1.weight.shape[0], mod.conv1.weight.shape[1]
-    b = Block()
-    b.N, b.Hi, b.Wi, b.Cin, b.P, b.stride, b.has_down = N, Hi, Wi, cin, p, mod.stride, 0
-    b.eps1, b.mom1, b.eps2, b.mom2, b.eps3, b.mom3 = bn1.eps, bn1.momentum, bn2.eps, bn2.momentum, bn3.eps, bn3.momentum
-    b.w1, b.g1, b.b1 = mod.conv1.weight.data_ptr(), bn1.weight.data_ptr(), bn1.bias.data_ptr()
-    b.w2, b.g2, b.b2 = mod.conv2.weight.data_ptr(), bn2.weight.data_ptr(), bn2.bias.data_ptr()
-    b.w3, b.g3, b.b3 = mod.conv3.weight.data_ptr(), bn3.weight.data_ptr(), bn3.bias.data_ptr()
-    b.rm1, b.rv1 = bn1.running_mean.data_ptr(), bn1.running_var.data_ptr()
-    b.rm2, b.rv2 = bn2.running_mean.data_ptr(), bn2.running_var.data_ptr()
-    b.rm3, b.rv3 = bn3.running_mean.data_ptr(), bn3.running_var.data_ptr()
-    key = (N, Hi, Wi, cin, p, mod.stride)
-    sz_ = _block_sizes.get(key)
-    if sz_ is None:
-        h, _ = _fns()
-        sv, sc = C.c_size_t(), C.c_size_t()
-        offs = (C.c_long * 8)()
-        _chk(h.scnattn_block_sizes(C.byref(b), C.byref(sv), C.byref(sc), offs), "scnattn_block_sizes")
-        sz_ = _block_sizes[key] = (sv.value, sc.value, tuple(offs))
-    return b, sz_
-
-
-class _BlockFnC(torch.autograd.Function):
-    """An identity Bottleneck (no downsample, stride 1) through csrc/bottleneck.cpp: ONE C call enqueues the ~15 forward
-    kernels, ONE the ~25 backward kernels (3x3 conv2 forward / d input as implicit GEMMs of the same kernel family);
-    only conv2's weight gradient is left to MIOpen, on the side stream."""
-
-    @staticmethod
-    def forward(ctx, mod, x, w1, g1, b1, w2, g2, b2, w3, g3, b3):
-        h, raw_stream = _fns()
-        dev = x.device
-        st = raw_stream(dev.index)
-        ws, part, bnpart = _buffers(dev)
-        if not x.is_contiguous(memory_format=torch.channels_last):
-            x = x.contiguous(memory_format=torch.channels_last)
-        N, Cin, Hi, Wi = x.shape
-        blk, (svf, scf, offs) = _block_struct(mod, N, Hi, Wi)
-        saved = torch.empty(svf, device=dev, dtype=torch.float32)
-        out = torch.empty((N * Hi * Wi, Cin), device=dev, dtype=torch.float32)
-        _chk(h.scnattn_block_fwd(st, C.byref(blk), x.data_ptr(), saved.data_ptr(), out.data_ptr(), ws.data_ptr(),
-                                 ws.numel(), part.data_ptr(), bnpart.data_ptr()), "scnattn_block_fwd")
-        ctx.mod = mod
-        ctx.geom = (N, Cin, Hi, Wi)
-        ctx.save_for_backward(x, saved, out, w1, g1, b1, w2, g2, b2, w3, g3, b3)
-        return _as4d(out, N, Hi, Wi)
-
-    @staticmethod
-    def backward(ctx, dout):
-        from ._lib import BlockGrads
-        h, raw_stream = _fns()
-        x, saved, out, w1, g1, b1, w2, g2, b2, w3, g3, b3 = ctx.saved_tensors
-        mod = ctx.mod
-        N, Cin, Hi, Wi = ctx.geom
-        dev = x.device
-        st = raw_stream(dev.index)
-        ws, part, bnpart = _buffers(dev)
-        need = ctx.needs_input_grad      # (mod, x, w1, g1, b1, w2, g2, b2, w3, g3, b3)
-        if dout.dtype != torch.float32 or not dout.is_contiguous(memory_format=torch.channels_last):
-            dout = dout.float().contiguous(memory_format=torch.channels_last)
-        blk, (svf, scf, offs) = _block_struct(mod, N, Hi, Wi)
-        p = blk.P
-        R = N * Hi * Wi
-        main = torch.cuda.current_stream(dev)
-        slot = _scratch(dev, scf, main)
-        scratch = slot[0]
-        dx = torch.empty((R, Cin), device=dev, dtype=torch.float32)      # always: it first receives d identity
-        dw1 = _grad_out(w1) if need[2] else None
-        dw3 = _grad_out(w3) if need[8] else None
-        gr = BlockGrads(None if dw1 is None else dw1.data_ptr(), None if dw3 is None else dw3.data_ptr())
-        side = _side(dev) if side_ok(w1, w2, w3) else None
-        if side is not None:
-            for t_ in (saved, x):
-                t_.record_stream(side.stream)
-        def run(phase):
-            _chk(h.scnattn_block_bwd(st, None if side is None else side.stream.cuda_stream, C.byref(blk), x.data_ptr(),
-                                     saved.data_ptr(), out.data_ptr(), dout.data_ptr(), scratch.data_ptr(), dx.data_ptr(),
-                                     C.byref(gr), ws.data_ptr(), None if side is None else side.ws.data_ptr(), ws.numel(),
-                                     part.data_ptr(), bnpart.data_ptr(), phase), "scnattn_block_bwd")
-
-        dw2 = None
-        if need[5]:      # conv2's weight gradient: MIOpen, on the side stream, as soon as dz2 (scratch) exists
-            run(1)
-            a1_4 = _as4d(saved[offs[0]:offs[0] + R * p].view(R, p), N, Hi, Wi)
-            dz2_4 = _as4d(scratch[offs[1]:offs[1] + R * p].view(R, p), N, Hi, Wi)
-            if side is not None:
-                side.fork(main)
-                with torch.cuda.stream(side.stream):
-                    dw2 = torch.ops.aten.convolution_backward(dz2_4, a1_4, w2, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                                              [False, True, False])[1]
-            else:
-                dw2 = torch.ops.aten.convolution_backward(dz2_4, a1_4, w2, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                                          [False, True, False])[1]
-            run(2)
-        else:
-            run(0)
-        if side is not None:
-            side.mark()
-            slot[1] = side.pending        # the ring slot may be rewritten once the side stream got here
-        # the BatchNorm gradients leave the ring slot (it is rewritten two blocks later): one small copy
-        gb = scratch[offs[5]:offs[5] + 12 * p].clone()
-        db1, dg1, db2, dg2 = gb[0:p], gb[p:2 * p], gb[2 * p:3 * p], gb[3 * p:4 * p]
-        db3, dg3 = gb[4 * p:8 * p], gb[8 * p:12 * p]
-        return (None, _as4d(dx, N, Hi, Wi) if need[1] else None, dw1, dg1 if need[3] else None, db1 if need[4] else None,
-                dw2, dg2 if need[6] else None, db2 if need[7] else None, dw3, dg3 if need[9] else None,
-                db3 if need[10] else None)
-
-
 def usable(mod, x):
     """The fused path covers what the train step runs: fp32 CUDA maps, BatchNorm in training mode with running
     statistics and affine parameters, widths that the 16-byte LDS-DMA granules can address."""
@@ -668,6 +481,15 @@ def usable(mod, x):
     p, cin = mod.conv1.weight.shape[0], mod.conv1.weight.shape[1]
     if p % 16 or cin % 16 or mod.conv2.groups != 1 or mod.conv2.dilation != (1, 1):
         return False
+    if mod.conv2.kernel_size != (3, 3) or mod.conv2.padding != (1, 1) or mod.stride not in (1, 2) \
+            or not mod.conv2.weight.is_contiguous(memory_format=torch.channels_last):
+        return False
+    if CONV3 == "hip":      # what the 3x3 kernels address: 32-channel blocks (stride 1), 128-channel
+        H, W = x.shape[2], x.shape[3]      # column tiles and even maps (stride 2)
+        if mod.stride == 1 and p % 32:
+            return False
+        if mod.stride == 2 and (p % 128 or H % 2 or W % 2):
+            return False
     if mod.downsample is not None:
         d0, d1 = mod.downsample[0], mod.downsample[1]
         if d0.kernel_size != (1, 1) or d0.stride != (mod.stride, mod.stride) or d1.weight is None or d1.momentum is None:
@@ -684,11 +506,5 @@ def bottleneck(mod, x):
         wd, gd, bd = mod.downsample[0].weight, mod.downsample[1].weight, mod.downsample[1].bias
     else:
         wd = gd = bd = None
-        # (64-channel 3x3 convolutions -- layer1 -- are the one shape where MIOpen's kernel wins clearly: those blocks
-        #  keep the per-call path with its autotuned conv2)
-        if _use_c_driver() and mod.stride == 1 and mod.conv2.weight.is_contiguous(memory_format=torch.channels_last) \
-                and mod.conv1.weight.shape[1] == 4 * mod.conv1.weight.shape[0] and mod.conv1.weight.shape[0] >= 128:
-            return _BlockFnC.apply(mod, x, mod.conv1.weight, mod.bn1.weight, mod.bn1.bias, mod.conv2.weight,
-                                   mod.bn2.weight, mod.bn2.bias, mod.conv3.weight, mod.bn3.weight, mod.bn3.bias)
     return _BottleneckFn.apply(mod, x, mod.conv1.weight, mod.bn1.weight, mod.bn1.bias, mod.conv2.weight, mod.bn2.weight,
                                mod.bn2.bias, mod.conv3.weight, mod.bn3.weight, mod.bn3.bias, wd, gd, bd)

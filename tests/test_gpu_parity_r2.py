@@ -524,11 +524,10 @@ def test_fused_bottleneck_vs_fp64(dev, name, inplanes, planes, stride, H, small,
         g = copy.deepcopy(m).to(dev).to(memory_format=torch.channels_last).train()
         xg = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
         SC.ENABLED = fused
-        # identity blocks: conv3 == "hip" -> the whole-block C drivers (scnattn_block_fwd/bwd), "miopen" -> the per-call
-        # path with MIOpen's conv2; blocks with a downsample branch always take the per-call path
-        saved_driver, saved_conv3 = SC.C_DRIVER, SC.CONV3
-        SC.C_DRIVER = conv3 == "hip"
-        SC.CONV3 = conv3        # conv2: the implicit-GEMM 3x3 mode of csrc/cgemm.hip (forward + stride-1 d input) or MIOpen
+        # conv2: "hip" = the product path (implicit-GEMM forward, d input by flipped taps / parity classes, halo-staged or
+        # gathered d weight: no library kernel in the block); "miopen" = the A/B mode with MIOpen's conv2
+        saved_conv3 = SC.CONV3
+        SC.CONV3 = conv3
         try:
             assert SC.usable(g, xg) == fused
             y = g(xg)
@@ -537,7 +536,6 @@ def test_fused_bottleneck_vs_fp64(dev, name, inplanes, planes, stride, H, small,
         finally:
             SC.ENABLED = True
             SC.CONV3 = saved_conv3
-            SC.C_DRIVER = saved_driver
         res[fused] = (y.detach(), xg.grad.detach(), {k: p.grad.detach() for k, p in g.named_parameters()},
                       {k: b.detach().clone() for k, b in g.named_buffers()})
     rep = []
@@ -1110,34 +1108,3 @@ def test_tagger_beside_the_encoder_gives_the_same_step(dev):
         for k in res["inline"][2]:
             assert rel_err(res[key][2][k], res["inline"][2][k]) <= 1e-3, "tagger statistics %s differ (%s)" % (k, key)
     _report(rep, "tagger forward on the side stream beside the caption encoder vs in line")
-
-
-def test_conv3_autotune_mode(dev):
-    """SCNATTN_CONV3=auto, the product default (the tests otherwise pin "hip", conftest.py): the first call of a shape
-    times the hand-written 3x3 convolution against MIOpen and records a choice per (kind, shape); whatever it picks,
-    the block's output and gradients agree with the pinned-"hip" run to fp32 accuracy."""
-    import copy
-    from scnattn.resnet import Bottleneck
-    from scnattn import conv as SC
-    torch.manual_seed(4)
-    blk = Bottleneck(1024, 256).to(dev).to(memory_format=torch.channels_last).train()
-    x = torch.randn(4, 1024, 8, 8, device=dev).contiguous(memory_format=torch.channels_last)
-    w = torch.randn(4, 1024, 8, 8, device=dev).contiguous(memory_format=torch.channels_last)
-    saved = SC.CONV3
-    res = {}
-    try:
-        for mode in ("hip", "auto"):
-            SC.CONV3 = mode
-            m = copy.deepcopy(blk)
-            xg = x.clone().requires_grad_(True)
-            y = m(xg)
-            (y * w).sum().backward()
-            res[mode] = (y.detach(), xg.grad.detach(), {k: p.grad.detach() for k, p in m.named_parameters()})
-        choices = {k: v for k, v in SC.conv3_choices().items() if k[1:4] == (4, 8, 8)}
-        assert {k[0] for k in choices} == {"fwd", "dgrad"} and set(choices.values()) <= {"hip", "miopen"}, choices
-    finally:
-        SC.CONV3 = saved
-    _ok(res["auto"][0], res["hip"][0], 1e-5, "output")
-    _ok(res["auto"][1], res["hip"][1], 1e-4, "d x")
-    for k in res["hip"][2]:
-        _ok(res["auto"][2][k], res["hip"][2][k], 1e-4, k)

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(h, name), "libscnattn.so does not export " + name
     assert set(L.EXPORTS) <= declared | {"scnattn_last_error"}
-    assert h.scnattn_version() == 106
+    assert h.scnattn_version() == 107
 
 
 def test_invalid_arguments_return_codes_and_messages():
@@ -467,3 +467,47 @@ def test_bench_starts_its_own_ranks_when_launched_bare(monkeypatch):
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
     assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+
+
+def test_flat_gradient_view_is_stolen_once_and_accumulated_after():
+    """ADVICE r2 (conv.py:285 / :410): a backward node that writes a weight gradient straight into the parameter's
+    slice of the flat gradient buffer must (1) return a FRESH alias so that AccumulateGrad steals it instead of
+    cloning it, (2) use the slice only for the first gradient of a sweep into an empty .grad -- a second backward
+    without zero_grad, or a weight used twice in one graph, must ACCUMULATE (old + new), not double the new one."""
+    import torch
+    from scnattn import conv as CV
+    from scnattn.flat import FlatBuffer
+
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, w, x):
+            ctx.w, ctx.x = w, x
+            return (w * x).sum()
+
+        @staticmethod
+        def backward(ctx, g):
+            out = CV._grad_out(ctx.w)
+            out.copy_(ctx.x * g)          # what the wgrad kernel does: overwrite, never accumulate
+            return out, None
+
+    w = torch.nn.Parameter(torch.randn(4, 3))
+    flat = FlatBuffer([w])
+    gv = flat.gviews[0]
+    x1, x2 = torch.randn(4, 3), torch.randn(4, 3)
+    Fn.apply(w, x1).backward()
+    assert w.grad.data_ptr() == gv.data_ptr(), "autograd cloned the flat view instead of stealing the alias"
+    assert torch.equal(gv, x1)
+    # second backward WITHOUT zero_grad: accumulate
+    Fn.apply(w, x2).backward()
+    assert torch.allclose(w.grad, x1 + x2)
+    # after gather (p.grad IS the flat view) and no zero_grad: still accumulates
+    flat.gather()
+    assert w.grad.data_ptr() == gv.data_ptr()
+    Fn.apply(w, x2).backward()
+    assert torch.allclose(w.grad, x1 + 2 * x2)
+    # one weight used twice in one graph
+    flat.zero_grad()
+    (Fn.apply(w, x1) + Fn.apply(w, x2)).backward()
+    assert torch.allclose(w.grad, x1 + x2)
+    flat.gather()
+    assert torch.allclose(gv, x1 + x2)

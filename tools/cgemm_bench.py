@@ -210,23 +210,76 @@ def check3():
         y = conv3(x, w, s)
         e = rel(y, ref.permute(0, 2, 3, 1).reshape(-1, Cout)); assert e < 3e-6, ("conv3 fwd", N, H, Cin, Cout, s, e)
         dy = torch.randn(N, Cout, Ho, Ho, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
-        gi, gw = torch.autograd.grad(F.conv2d(x.double().requires_grad_(True), w.double().requires_grad_(True), stride=s, padding=1),
-                                     [], dy.double(), allow_unused=True) if False else (None, None)
         xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
         F.conv2d(xd, wd, stride=s, padding=1).backward(dy.double())
-        if Cin % 128 == 0:
+        if Cin % 128 == 0:      # the gathered form (k_slices < 0 forces it for stride 1 too)
             dw = torch.empty_like(w)
-            call("scnattn_conv3x3_wgrad", stream_of(x), N, H, H, Cin, Cout, s, ptr(dy), ptr(x), ptr(dw), ptr(WS), WS.numel())
-            e = rel(dw, wd.grad); assert e < 1e-5, ("conv3 wgrad", N, H, Cin, Cout, s, e)
+            call("scnattn_conv3x3_wgrad", stream_of(x), N, H, H, Cin, Cout, s, ptr(dy), ptr(x), ptr(dw), ptr(WS), WS.numel(), -1)
+            e = rel(dw, wd.grad); assert e < 1e-5, ("conv3 wgrad gather", N, H, Cin, Cout, s, e)
         if s == 1:
             dx = torch.empty_like(x)
             call("scnattn_conv3x3_dgrad", stream_of(x), N, H, H, Cin, Cout, ptr(dy), ptr(w), ptr(dx), None, ptr(WS), WS.numel())
             e = rel(dx, xd.grad); assert e < 3e-6, ("conv3 dgrad", N, H, Cin, Cout, e)
+    # halo-staged weight gradient (csrc/conv3.hip): strips of 16 and of 8 columns, non-square maps, every K split incl.
+    # wave ranges that start in the middle of a strip, Cin != Cout
+    for (N, H, W, Cin, Cout) in [(2, 8, 8, 128, 128), (3, 16, 16, 64, 96), (2, 32, 32, 32, 64), (2, 6, 24, 64, 32), (5, 7, 16, 96, 32),
+                                 (1, 3, 40, 32, 32), (4, 8, 8, 512, 512), (32, 16, 16, 256, 256),
+                                 (2, 4, 4, 256, 256), (2, 2, 2, 512, 512), (3, 5, 12, 64, 64), (2, 9, 20, 32, 96)]:      # ragged last strips
+        x = torch.randn(N, Cin, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        dy = torch.randn(N, Cout, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        w = torch.zeros(Cout, Cin, 3, 3, device=dev).contiguous(memory_format=torch.channels_last)
+        ref = torch.ops.aten.convolution_backward(dy.double(), x.double(), w.double(), None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                  [False, True, False])[1]
+        for ksl in (0, 1, 2, 3, 7):
+            nseg_lines = N * (W // 16 if W % 16 == 0 else (W + 7) // 8) * H
+            if ksl > max(1, nseg_lines // 16) or ksl * Cout * 9 * Cin > WS.numel():
+                continue
+            dw = torch.full_like(w, float("nan"))
+            call("scnattn_conv3x3_wgrad", stream_of(x), N, H, W, Cin, Cout, 1, ptr(dy), ptr(x), ptr(dw), ptr(WS), WS.numel(), ksl)
+            e = rel(dw, ref); assert e < 1e-5, ("conv3 wgrad halo", N, H, W, Cin, Cout, ksl, e)
+    # d input of the stride-2 convolutions: four parity classes in one launch
+    for (N, Hi, Wi, Cin, Cout) in [(2, 8, 8, 128, 128), (3, 16, 16, 64, 32), (2, 12, 20, 48, 64), (1, 4, 6, 256, 16), (32, 16, 16, 512, 512)]:
+        w = (0.1 * torch.randn(Cout, Cin, 3, 3, generator=g)).to(dev).contiguous(memory_format=torch.channels_last)
+        dy = torch.randn(N, Cout, Hi // 2, Wi // 2, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        x0 = torch.zeros(N, Cin, Hi, Wi, device=dev, dtype=torch.float64)
+        ref = torch.ops.aten.convolution_backward(dy.double(), x0, w.double(), None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
+                                                  [True, False, False])[0]
+        dx = torch.full((N, Cin, Hi, Wi), float("nan"), device=dev).contiguous(memory_format=torch.channels_last)
+        call("scnattn_conv3x3_dgrad_strided", stream_of(dy), N, Hi, Wi, Cin, Cout, 2, ptr(dy), ptr(w), ptr(dx), ptr(WS), WS.numel())
+        e = rel(dx, ref); assert e < 3e-6, ("conv3 dgrad strided", N, Hi, Wi, Cin, Cout, e)
     print("check3 ok", flush=True)
 
 
+def checkstem():
+    g = torch.Generator(device="cpu").manual_seed(2)
+    for (N, H, W, cl_x, cl_w) in [(2, 64, 64, False, True), (3, 50, 70, True, True), (1, 33, 17, False, False), (32, 256, 256, True, True)]:
+        x = torch.randn(N, 3, H, W, generator=g).to(dev)
+        w = (0.1 * torch.randn(64, 3, 7, 7, generator=g)).to(dev)
+        if cl_x: x = x.contiguous(memory_format=torch.channels_last)
+        if cl_w: w = w.contiguous(memory_format=torch.channels_last)
+        Hz, Wz = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        nt = lib().scnattn_stem_tiles(N, H, W)
+        z = torch.full((N * Hz * Wz, 64), float("nan"), device=dev)
+        part = torch.full((nt, 2, 64), float("nan"), device=dev)
+        sft = (0.1 * torch.randn(64, generator=g)).to(dev)
+        call("scnattn_stem_conv7", stream_of(x), N, H, W, ptr(x), *x.stride(), ptr(w), *w.stride(), ptr(z), ptr(part), ptr(sft))
+        ref = F.conv2d(x.double(), w.double(), stride=2, padding=3).permute(0, 2, 3, 1).reshape(-1, 64)
+        e = rel(z, ref); assert e < 3e-6, ("stem conv7", N, H, W, e)
+        d = ref - sft.double()
+        e1 = rel(part[:, 0].double().sum(0), d.sum(0)); e2 = rel(part[:, 1].double().sum(0), (d * d).sum(0))
+        assert e1 < 2e-5 and e2 < 2e-5, ("stem stats", N, H, W, e1, e2)
+        ss = torch.stack([1 + 0.5 * torch.randn(64, generator=g), 0.3 * torch.randn(64, generator=g)], dim=1).to(dev).contiguous()
+        Hp, Wp = (Hz - 1) // 2 + 1, (Wz - 1) // 2 + 1
+        out = torch.full((N * Hp * Wp, 64), float("nan"), device=dev)
+        call("scnattn_stem_bn_relu_maxpool", stream_of(x), N, Hz, Wz, 64, ptr(z), ptr(ss), ptr(out))
+        a = torch.relu(z.view(N, Hz, Wz, 64) * ss[:, 0] + ss[:, 1]).permute(0, 3, 1, 2)
+        pref = F.max_pool2d(a, 3, 2, 1).permute(0, 2, 3, 1).reshape(-1, 64)
+        assert torch.allclose(out, pref, rtol=1e-6, atol=1e-6), ("stem pool", N, H, W, (out - pref).abs().max().item())
+    print("checkstem ok", flush=True)
+
+
 def time3():
-    print("3x3: layer (N,H,Cin,Cout,s) | fwd new / miopen (TF new) | dgrad new / miopen | wgrad new / miopen")
+    print("3x3: layer (N,H,Cin,Cout,s) | fwd new / miopen (TF new) | dgrad new / miopen | wgrad halo (policy) / gather / miopen | halo at k_slices 1 2 4 8 16 32")
     for name, H, Cin, s in [("l1", 64, 64, 1), ("l2.0", 64, 128, 2), ("l2", 32, 128, 1), ("l3.0", 32, 256, 2), ("l3", 16, 256, 1),
                             ("l4.0", 16, 512, 2), ("l4", 8, 512, 1)]:
         N, Cout = 32, Cin
@@ -237,12 +290,37 @@ def time3():
         y = torch.empty(N * Ho * Ho, Cout, device=dev); dx = torch.empty_like(x); dw = torch.empty_like(w)
         f0 = t_us(lambda: call("scnattn_conv3x3_fwd", stream_of(x), N, H, H, Cin, Cout, s, ptr(x), ptr(w), ptr(y), None, ptr(WS), WS.numel()))
         f1 = t_us(lambda: F.conv2d(x, w, stride=s, padding=1))
-        g0 = t_us(lambda: call("scnattn_conv3x3_dgrad", stream_of(x), N, H, H, Cin, Cout, ptr(dy), ptr(w), ptr(dx), None, ptr(WS), WS.numel())) if s == 1 else float("nan")
+        if s == 1:
+            g0 = t_us(lambda: call("scnattn_conv3x3_dgrad", stream_of(x), N, H, H, Cin, Cout, ptr(dy), ptr(w), ptr(dx), None, ptr(WS), WS.numel()))
+        else:
+            g0 = t_us(lambda: call("scnattn_conv3x3_dgrad_strided", stream_of(x), N, H, H, Cin, Cout, s, ptr(dy), ptr(w), ptr(dx), ptr(WS), WS.numel()))
         g1 = t_us(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False]))
-        h0 = t_us(lambda: call("scnattn_conv3x3_wgrad", stream_of(x), N, H, H, Cin, Cout, s, ptr(dy), ptr(x), ptr(dw), ptr(WS), WS.numel())) if Cin % 128 == 0 else float("nan")
+        wg = lambda ksl: t_us(lambda: call("scnattn_conv3x3_wgrad", stream_of(x), N, H, H, Cin, Cout, s, ptr(dy), ptr(x), ptr(dw), ptr(WS), WS.numel(), ksl))
+        h0 = wg(0) if s == 1 else float("nan")
+        h2 = wg(-1) if Cin % 128 == 0 else float("nan")
         h1 = t_us(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False]))
+        sw = []
+        if s == 1:
+            for ksl in (1, 2, 4, 8, 16, 32):
+                lines = N * (H // (16 if H % 16 == 0 else 8)) * H
+                sw.append(wg(ksl) if (ksl <= max(1, lines // 16) and ksl * Cout * 9 * Cin <= WS.numel()) else float("nan"))
         fl = 2.0 * N * Ho * Ho * Cout * 9 * Cin
-        print("%-5s (%d,%d,%d,%d,%d) | %7.1f / %7.1f (%5.1f TF) | %7.1f / %7.1f | %7.1f / %7.1f" % (name, N, H, Cin, Cout, s, f0, f1, fl / f0 / 1e6, g0, g1, h0, h1), flush=True)
+        print("%-5s (%d,%d,%d,%d,%d) | %7.1f / %7.1f (%5.1f TF) | %7.1f / %7.1f | %7.1f / %7.1f / %7.1f | %s"
+              % (name, N, H, Cin, Cout, s, f0, f1, fl / f0 / 1e6, g0, g1, h0, h2, h1, " ".join("%6.1f" % t for t in sw)), flush=True)
+    # the stem
+    N, H = 32, 256
+    x = torch.randn(N, 3, H, H, device=dev).contiguous(memory_format=torch.channels_last)
+    w = (0.1 * torch.randn(64, 3, 7, 7, device=dev)).contiguous(memory_format=torch.channels_last)
+    z = torch.empty(N * 128 * 128, 64, device=dev); out = torch.empty(N * 64 * 64, 64, device=dev)
+    nt = lib().scnattn_stem_tiles(N, H, H)
+    part = torch.empty(nt, 2, 64, device=dev); ss = torch.rand(64, 2, device=dev)
+    c0 = t_us(lambda: call("scnattn_stem_conv7", stream_of(x), N, H, H, ptr(x), *x.stride(), ptr(w), *w.stride(), ptr(z), ptr(part), None))
+    c1 = t_us(lambda: F.conv2d(x, w, stride=2, padding=3))
+    p0 = t_us(lambda: call("scnattn_stem_bn_relu_maxpool", stream_of(x), N, 128, 128, 64, ptr(z), ptr(ss), ptr(out)))
+    z4 = z.view(N, 128, 128, 64).permute(0, 3, 1, 2)
+    p1 = t_us(lambda: F.max_pool2d(z4, 3, 2, 1))
+    print("stem: conv7 + stats %7.1f us (miopen conv %7.1f) (%5.1f TF) | bn+relu+maxpool %7.1f us (aten maxpool alone %7.1f)"
+          % (c0, c1, 2.0 * N * 128 * 128 * 64 * 147 / c0 / 1e6, p0, p1), flush=True)
 
 
 def ab():
@@ -337,7 +415,7 @@ def sweepw():
         ts = []
         for mi, tgt in combos:
             SF.set_option("cgemm_mi", mi); SF.set_option("cgemm_target", tgt)
-            ts.append(t_us(lambda: call("scnattn_conv3x3_wgrad", stream_of(x), N, H, H, Cin, Cout, 1, ptr(dy), ptr(x), ptr(dw), ptr(WS), WS.numel())))
+            ts.append(t_us(lambda: call("scnattn_conv3x3_wgrad", stream_of(x), N, H, H, Cin, Cout, 1, ptr(dy), ptr(x), ptr(dw), ptr(WS), WS.numel(), -1)))
         SF.set_option("cgemm_mi", 0); SF.set_option("cgemm_target", 512)
         m = t_us(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False]))
         print("%-3s " % name + " " * 19 + " ".join("%10.1f" % t for t in ts) + " | %8.1f" % m, flush=True)
@@ -406,5 +484,7 @@ if __name__ == "__main__":
         ab()
     if what in ("check3", "all3"):
         check3()
+    if what in ("checkstem", "all3"):
+        checkstem()
     if what in ("time3", "all3"):
         time3()
