@@ -287,8 +287,8 @@ int scnattn_bn_bwd(void* stream, int R, int C, const void* dy, const void* y, co
  *   pro_ss [Cin][2] = {scale, shift} (fwd, wgrad): the input operand is taken as relu(x * scale[c] + shift[c]) --
  *       the previous BatchNorm + ReLU folded to one fma per element (scale = gamma*invstd, shift = beta - mean*scale,
  *       written interleaved by scnattn_bn_finalize) -- so the normalised map is never written to or read from HBM;
- *   stat_partial [scnattn_cgemm_row_tiles(R)][2][Cout] (fwd): per 64-row block and output channel, sum(y - s) and
- *       sum((y - s)^2) with s = stat_shift[c] (or 0): the statistics pass of the NEXT BatchNorm, fixed order;
+ *   stat_partial [2][Cout][scnattn_cgemm_stat_ld(R)] (fwd; channel-major): per output channel and 64-row block, sum(y - s)
+ *       and sum((y - s)^2) with s = stat_shift[c] (or 0): the statistics pass of the NEXT BatchNorm, fixed order;
  *   ez / emean / einvstd / egamma / ebeta (dgrad): the result is masked with the ReLU mask recomputed from the
  *       BatchNorm input z ([R][Cin], leading dimension ldz), g = dx * [fma((z-mean)*invstd, gamma, beta) > 0] -- or,
  *       when pro_ss is given, * [fma(z, scale, shift) > 0], bit for bit the mask of what a forward prologue computed --
@@ -353,7 +353,7 @@ int scnattn_conv3x3_wgrad(void* stream, int N, int Hi, int Wi, int Cin, int Cout
  * children 0..3 of the trunk behind models/encoders/caption.py:17-22; frozen in every configuration of the reference, so
  * forward only.  x is the (N,3,H,W) image batch in ANY memory format (element strides sn, sc, sh, sw), w the (64,3,7,7)
  * weight in any format (wn, wc, wh, ww).  scnattn_stem_conv7 writes z [N*Ho*Wo][64] (Ho = (H-1)/2+1) and, when
- * stat_partial is given, per-workgroup sums {sum(z - s), sum((z - s)^2)} [scnattn_stem_tiles(N,H,W)][2][64] for
+ * stat_partial is given, per-workgroup sums {sum(z - s), sum((z - s)^2)} [2][64][(scnattn_stem_tiles(N,H,W)+3)&~3] for
  * scnattn_bn_finalize (s = stat_shift[c] or 0).  scnattn_stem_bn_relu_maxpool: out [N*Hp*Wp][C] = max over the 3x3 window
  * of relu(z*scale[c] + shift[c]) with ss [C][2] = {scale, shift} (scnattn_bn_finalize's ss_out), Hp = (Hz-1)/2+1. */
 int scnattn_stem_tiles(int N, int H, int W);
@@ -361,53 +361,40 @@ int scnattn_stem_conv7(void* stream, int N, int H, int W, const float* x, long s
                        const float* w, long wn, long wc, long wh, long ww, float* z, float* stat_partial,
                        const float* stat_shift);
 int scnattn_stem_bn_relu_maxpool(void* stream, int N, int Hz, int Wz, int C, const float* z, const float* ss, float* out);
-/* ---- whole-block drivers (csrc/bottleneck.cpp): ONE call enqueues every kernel of a Bottleneck's forward pass, ONE its
- * backward pass -- torchvision's Bottleneck behind models/encoders/caption.py:17-22, out = relu(bn3(conv3(relu(bn2(
- * conv2(relu(bn1(conv1(x)))))))) + identity) with BatchNorm in training mode -- the way scnattn_seq_fwd/bwd do for the
- * decoder's time loop.  fp32 channels-last maps ([N*H*W][C]); w1 [P][Cin], w2 [P][3][3][P], w3 [4P][P], wd [4P][Cin]
- * (channels-last conv weights); rm1.. / rv1.. = running mean / variance (updated with mom1..), eps / mom per BatchNorm.
- * Workspaces come from the caller (scnattn_block_sizes): `saved` carries the forward state to the backward pass,
- * `scratch` is free after the call; ws / ws_side = split-K slabs of the GEMMs on the main / side stream (>= 16 Mi
- * floats), part >= 2 Mi floats, bnpart >= scnattn_bn_workspace_floats(4P). */
-typedef struct scnattn_block {
-    int N, Hi, Wi, Cin, P, stride, has_down;      /* P = planes; output channels = 4P */
-    float eps1, mom1, eps2, mom2, eps3, mom3, epsd, momd;
-    const float *w1, *g1, *b1, *w2, *g2, *b2, *w3, *g3, *b3, *wd, *gd, *bd;
-    float *rm1, *rv1, *rm2, *rv2, *rm3, *rv3, *rmd, *rvd;
-} scnattn_block;
-/* weight gradients the backward driver writes itself (NULL = skip); the BatchNorm gradients are left in `scratch` at
- * offsets[5] as {dbeta1 [P], dgamma1 [P], dbeta2, dgamma2, dbeta3 [4P], dgamma3 [4P]} */
-typedef struct scnattn_block_grads {
-    float *dw1, *dw3;
-} scnattn_block_grads;
-/* offsets (floats): [0] a1 in saved, [1] dz2 in scratch (both inputs of the 3x3 weight gradient, which the caller
- * runs), [2] z2, [3] z1, [4] z3 in saved, [5] BatchNorm gradients in scratch, [6] dz3, [7] dz1 in scratch */
-int scnattn_block_sizes(const scnattn_block* b, size_t* saved_floats, size_t* scratch_floats, long offsets[8]);
-int scnattn_block_fwd(void* stream, const scnattn_block* b, const float* x, float* saved, float* out, float* ws,
-                      long ws_floats, float* part, float* bnpart);
-/* identity blocks only (no downsample, stride 1).  dx [N*Hi*Wi][Cin] may be NULL; the two 1x1 weight gradients run on
- * side_stream (NULL: on `stream`), forked by events once their inputs exist -- the caller joins before reading them. */
-int scnattn_block_bwd(void* stream, void* side_stream, const scnattn_block* b, const float* x, const float* saved,
-                      const float* out, const float* dout, float* scratch, float* dx, const scnattn_block_grads* gr,
-                      float* ws, float* ws_side, long ws_floats, float* part, float* bnpart, int phase);
-/* phase 0: the whole backward pass; 1: up to dz2 (so that the caller can start conv2's weight gradient, the longest one,
- * as early as its inputs exist); 2: the rest. */
-/* BatchNorm statistics from partial[nchunk][2][C] = {sum(x - s), sum((x - s)^2)} (s = shift[c] or 0), as written by
- * the statistics epilogue above: mean, 1/sqrt(var+eps), running-stat update (momentum; run_* may be NULL), and, when
- * ss_out is given, the folded {scale = gamma*invstd, shift = beta - mean*scale} pairs [C][2] for a consumer's prologue. */
-int scnattn_bn_finalize(void* stream, long R, int C, int nchunk, const float* partial, const float* shift, float eps,
-                        float momentum, float* mean, float* invstd, float* run_mean, float* run_var,
+/* ---- BatchNorm statistics that ride on the convolutions, finalized ON LOAD (csrc/batchnorm.hip) --------------------------
+ * The statistics epilogues above (and scnattn_stem_conv7, scnattn_bn_bwd_reduce, the dgrad mask pass) leave CHANNEL-MAJOR
+ * partials  partial[2][C][ldp]:  entry (which, channel, chunk), ldp = chunk count rounded up to 4
+ * (scnattn_cgemm_stat_ld(R) for a product of R rows: one chunk per 64 rows).  A dependent launch costs ~8-9 us on MI355X,
+ * so the tiny per-BatchNorm `finalize` launches are folded into the element-wise kernel that consumes the statistics:
+ * each of its workgroups owns 64 channels and sums their partial rows itself (fixed order: every workgroup gets the same
+ * bits), the workgroups of the first row chunk also write the per-channel results.
+ *   scnattn_bn_finalize    statistics only: mean, 1/sqrt(var+eps), running-stat update (momentum; run_* may be NULL) and,
+ *                          when ss_out is given, the folded {scale = gamma*invstd, shift = beta - mean*scale} pairs [C][2]
+ *                          for a consumer that normalises on load (conv3's prologue, the stem's pooling kernel);
+ *   scnattn_bn_apply_fin   y = [relu](gamma*(z-mean)*invstd + beta [+ res]) with the same finalize inside;
+ *                          partial holds {sum(z - s), sum((z - s)^2)}, s = shift[c] (NULL: 0).  `shift` must be the vector the
+ *                          producer's epilogue used and must NOT alias run_mean (this kernel updates it while other
+ *                          workgroups still read shift): callers pass the previous step's batch mean;
+ *   scnattn_bn_bwd_reduce  g = dy * [y > 0] (relu != 0) or dy -> gout (may be NULL); partial = {sum g, sum g*xhat};
+ *                          *nchunk_out = chunk count (ldp = that rounded up to 4 <= ldp_cap);
+ *   scnattn_bn_bwd_dx_fin  dz = gamma*invstd*(g - dbeta/R - xhat*dgamma/R) from an already masked g, dbeta = sum g and
+ *                          dgamma = sum g*xhat summed from the partials inside (and written out as the parameter gradients). */
+int scnattn_cgemm_stat_ld(int M);
+int scnattn_bn_finalize(void* stream, long R, int C, const float* partial, int ldp, int nchunk, const float* shift,
+                        float eps, float momentum, float* mean, float* invstd, float* run_mean, float* run_var,
                         const float* gamma, const float* beta, float* ss_out);
+int scnattn_bn_apply_fin(void* stream, long R, int C, const float* z, const float* res, const float* partial, int ldp,
+                         int nchunk, const float* shift, float eps, float momentum, const float* gamma, const float* beta,
+                         int relu, float* y, float* mean, float* invstd, float* run_mean, float* run_var, float* ss_out);
+int scnattn_bn_bwd_reduce(void* stream, int R, int C, const float* dy, const float* y, const float* z, const float* mean,
+                          const float* invstd, int relu, float* partial, int ldp_cap, float* gout, int* nchunk_out);
+int scnattn_bn_bwd_dx_fin(void* stream, long R, int C, const float* g, const float* z, const float* mean,
+                          const float* invstd, const float* gamma, const float* partial, int ldp, int nchunk, float* dbeta,
+                          float* dgamma, float* dz);
 /* scnattn_bn_stats (fp32 maps) that also writes the folded {scale, shift} pairs [C][2] for a consumer's prologue */
 int scnattn_bn_stats_fold(void* stream, int R, int C, const void* x, float eps, float momentum, float* partial,
                           float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma,
                           const float* beta, float* ss_out);
-/* The element-wise half of the BatchNorm backward on an already masked g (written, with its column sums, by the
- * dgrad mask epilogue): dz = gamma*invstd*(g - dbeta/R - xhat*dgamma/R) */
-int scnattn_bn_bwd_dx(void* stream, int R, int C, const float* g, const float* z, const float* mean, const float* invstd,
-                      const float* gamma, const float* dbeta, const float* dgamma, float* dz);
-/* dbeta[c] = sum_chunks partial[.][0][c], dgamma[c] = sum_chunks partial[.][1][c] (the mask epilogue's sums) */
-int scnattn_bn_bwd_finalize(void* stream, int C, int nchunk, const float* partial, float* dbeta, float* dgamma);
 
 /* ---- data-parallel gradient exchange (the reference has no distributed code) ---------------------
  * One process per GPU.  RCCL SUM all-reduce of gradient buckets on a library-owned communication stream, ordered

@@ -239,26 +239,37 @@ int scnattn_stem_bn_relu_maxpool(void* stream, int N, int Hz, int Wz, int C, con
     return stem_bn_relu_maxpool(ST(stream), N, Hz, Wz, C, z, ss, out);
 }
 
-int scnattn_bn_finalize(void* stream, long R, int C, int nchunk, const float* partial, const float* shift, float eps,
-                        float momentum, float* mean, float* invstd, float* run_mean, float* run_var,
+int scnattn_cgemm_stat_ld(int M) { return cgemm_stat_ld(M); }
+
+int scnattn_bn_finalize(void* stream, long R, int C, const float* partial, int ldp, int nchunk, const float* shift,
+                        float eps, float momentum, float* mean, float* invstd, float* run_mean, float* run_var,
                         const float* gamma, const float* beta, float* ss_out) {
-    return bn_finalize(ST(stream), R, C, nchunk, partial, shift, eps, momentum, mean, invstd, run_mean, run_var, gamma,
-                       beta, ss_out);
+    return bn_finalize_t(ST(stream), R, C, partial, ldp, nchunk, shift, eps, momentum, mean, invstd, run_mean, run_var, gamma,
+                         beta, ss_out);
+}
+
+int scnattn_bn_apply_fin(void* stream, long R, int C, const float* z, const float* res, const float* partial, int ldp,
+                         int nchunk, const float* shift, float eps, float momentum, const float* gamma, const float* beta,
+                         int relu, float* y, float* mean, float* invstd, float* run_mean, float* run_var, float* ss_out) {
+    return bn_apply_fin(ST(stream), R, C, z, res, partial, ldp, nchunk, shift, eps, momentum, gamma, beta, relu, y, mean,
+                        invstd, run_mean, run_var, ss_out);
+}
+
+int scnattn_bn_bwd_reduce(void* stream, int R, int C, const float* dy, const float* y, const float* z, const float* mean,
+                          const float* invstd, int relu, float* partial, int ldp_cap, float* gout, int* nchunk_out) {
+    return bn_bwd_reduce_t(ST(stream), R, C, dy, y, z, mean, invstd, relu, partial, ldp_cap, gout, nchunk_out);
+}
+
+int scnattn_bn_bwd_dx_fin(void* stream, long R, int C, const float* g, const float* z, const float* mean,
+                          const float* invstd, const float* gamma, const float* partial, int ldp, int nchunk, float* dbeta,
+                          float* dgamma, float* dz) {
+    return bn_bwd_dx_fin(ST(stream), R, C, g, z, mean, invstd, gamma, partial, ldp, nchunk, dbeta, dgamma, dz);
 }
 
 int scnattn_bn_stats_fold(void* stream, int R, int C, const void* x, float eps, float momentum, float* partial,
                           float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma,
                           const float* beta, float* ss_out) {
     return bn_stats(ST(stream), R, C, x, 0, eps, momentum, partial, mean, invstd, run_mean, run_var, gamma, beta, ss_out);
-}
-
-int scnattn_bn_bwd_dx(void* stream, int R, int C, const float* g, const float* z, const float* mean, const float* invstd,
-                      const float* gamma, const float* dbeta, const float* dgamma, float* dz) {
-    return bn_bwd_dx(ST(stream), R, C, g, z, mean, invstd, gamma, dbeta, dgamma, dz);
-}
-
-int scnattn_bn_bwd_finalize(void* stream, int C, int nchunk, const float* partial, float* dbeta, float* dgamma) {
-    return bn_bwd_finalize(ST(stream), C, nchunk, partial, dbeta, dgamma);
 }
 
 int scnattn_skinny_gemm(void* stream, int rows, int N, int K, int groups, const float* X, long ldx, long xg,

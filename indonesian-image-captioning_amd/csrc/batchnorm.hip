@@ -148,39 +148,6 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(int R, int C, int nchu
     }
 }
 
-// Same as bn_finalize_kernel for partials written by a GEMM statistics epilogue (shift vector instead of x[0][c]),
-// plus the folded scale/shift a consumer's prologue applies.
-__global__ __launch_bounds__(256) void bn_finalize_shift_kernel(long R, int C, int nchunk, const float* __restrict__ partial,
-                                                                const float* shift, float eps, float momentum,
-                                                                float* __restrict__ mean, float* __restrict__ invstd,
-                                                                float* run_mean, float* __restrict__ run_var,
-                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                float* __restrict__ ss_out) {
-    __shared__ float red[16][2][17];
-    const int c = blockIdx.x * 16 + (threadIdx.x & 15), lane16 = threadIdx.x >> 4;
-    float s1, s2;
-    reduce_partials16(partial, C, nchunk, c, lane16, red, s1, s2);
-    if (lane16 != 0 || c >= C) return;
-    const float inv_n = 1.f / (float)R;
-    const float m1 = s1 * inv_n;
-    const float mu = (shift ? shift[c] : 0.f) + m1;
-    float var = s2 * inv_n - m1 * m1;
-    if (var < 0.f) var = 0.f;
-    const float is = rsqrtf(var + eps);
-    mean[c] = mu;
-    invstd[c] = is;
-    if (run_mean) run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mu;
-    if (run_var) {
-        const float unbiased = R > 1 ? var * ((float)R / (float)(R - 1)) : var;
-        run_var[c] = (1.f - momentum) * run_var[c] + momentum * unbiased;
-    }
-    if (ss_out) {
-        const float sc = gamma[c] * is;
-        ss_out[2 * c] = sc;
-        ss_out[2 * c + 1] = fmaf(-mu, sc, beta[c]);
-    }
-}
-
 template <typename T, bool RELU, bool RES>
 __global__ __launch_bounds__(256) void bn_apply_kernel(long n4, int C, const T* __restrict__ z,
                                                        const T* __restrict__ res, const float* __restrict__ mean,
@@ -220,7 +187,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(int R, int C, int ro
                                                             const T* __restrict__ y, const T* __restrict__ z,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            float* __restrict__ partial, T* __restrict__ gout = nullptr) {
+                                                            float* __restrict__ partial, T* __restrict__ gout = nullptr,
+                                                            int ldp = 0) {      // ldp > 0: channel-major partial [2][C][ldp]
     __shared__ float red[16][2][64 + 1];
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.x * 64 + cl * 4;
@@ -278,8 +246,215 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(int R, int C, int ro
             float v = red[0][which][cc];
 #pragma unroll
             for (int i = 1; i < 16; ++i) v += red[i][which][cc];
-            partial[((long)blockIdx.y * 2 + which) * C + blockIdx.x * 64 + cc] = v;
+            if (ldp > 0) partial[((long)which * C + blockIdx.x * 64 + cc) * ldp + blockIdx.y] = v;
+            else partial[((long)blockIdx.y * 2 + which) * C + blockIdx.x * 64 + cc] = v;
         }
+    }
+}
+
+// ================= finalize on load: channel-major partials [2][C][ldp] ==========================================
+// The statistics epilogues of csrc/cgemm.hip (and cstats / bn_bwd_reduce / the stem) leave one partial per (channel,
+// 64-row block), channel-major.  A dependent launch costs ~8-9 us on this chip (4-5 us floor of a tiny kernel + the
+// boundary), a Bottleneck had six tiny `finalize` launches on its critical path; here the CONSUMER of the statistics --
+// an element-wise kernel that owns a block of 64 channels per workgroup -- sums the partials of its own channels while
+// its first map loads are in flight: 4 lanes per channel read contiguous 16-byte pieces of a channel's row, fixed order
+// (bit-reproducible, every workgroup of a column block computes the same bits).  The workgroups with blockIdx.y == 0
+// also write the per-channel results (mean / invstd / running statistics, or d beta / d gamma) for later kernels.
+__device__ __forceinline__ void reduce_partials_t(const float* __restrict__ partial, int C, int ldp, int nchunk, int c0,
+                                                  float (*out)[64]) {
+    const int ch = threadIdx.x >> 2, q = threadIdx.x & 3, c = c0 + ch;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(partial, (unsigned)(2L * C * ldp * 4));
+    float a = 0.f, b = 0.f;
+    const unsigned o1 = (unsigned)((long)c * ldp * 4), o2 = (unsigned)(((long)C + c) * ldp * 4);
+    for (int i0 = 4 * q; i0 < nchunk; i0 += 64) {          // 4 x 2 sixteen-byte loads in flight per lane
+        f32x4 u[4], v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = i0 + 16 * j;
+            const bool ok = c < C && i < nchunk;
+            u[j] = buf_load4(rs, ok ? o1 + (unsigned)i * 4u : OOB_OFF);
+            v[j] = buf_load4(rs, ok ? o2 + (unsigned)i * 4u : OOB_OFF);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = i0 + 16 * j;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {          // the row's padding past nchunk is never summed
+                a += (i + e < nchunk) ? u[j][e] : 0.f;
+                b += (i + e < nchunk) ? v[j][e] : 0.f;
+            }
+        }
+    }
+    a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64);
+    b += __shfl_xor(b, 1, 64); b += __shfl_xor(b, 2, 64);
+    if (q == 0) { out[0][ch] = a; out[1][ch] = b; }
+    __syncthreads();
+}
+
+struct BnFin {      // what a forward finalize produces besides the normalised map
+    const float* partial; int ldp, nchunk; const float* shift; float eps, momentum;
+    float* mean; float* invstd; float* run_mean; float* run_var; float* ss_out;
+};
+
+// y = [relu](gamma*(z-mean)*invstd + beta [+ res]) with mean / invstd computed here from the producer's partials.
+// grid (C/64 column blocks, row chunks).  `shift` must not alias anything this kernel writes (the caller hands over the
+// PREVIOUS step's batch mean, not the running mean this kernel updates).
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(256) void bn_apply_fin_kernel(long R, int C, int rows_per_chunk, const float* __restrict__ z,
+                                                           const float* __restrict__ res, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ y, BnFin f) {
+    __shared__ float st[2][64];
+    __shared__ float smu[64], sis[64];
+    const int c0 = blockIdx.x * 64;
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4, cq = min(c0 + cl * 4, C - 4);
+    const long r0 = (long)blockIdx.y * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+    // the first rows of the map do not depend on the statistics: in flight while the partials are summed
+    f32x4 v[4], rr[4];
+    long r = r0 + rl;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long off = min(r + 16 * j, r1 - 1) * C + cq;
+        v[j] = *reinterpret_cast<const f32x4*>(z + off);
+        if (RES) rr[j] = *reinterpret_cast<const f32x4*>(res + off);
+    }
+    reduce_partials_t(f.partial, C, f.ldp, f.nchunk, c0, st);
+    if (threadIdx.x < 64 && c0 + threadIdx.x < C) {
+        const int c = c0 + threadIdx.x;
+        const float inv_n = 1.f / (float)R;
+        const float m1 = st[0][threadIdx.x] * inv_n;
+        const float mu = (f.shift ? f.shift[c] : 0.f) + m1;
+        float var = st[1][threadIdx.x] * inv_n - m1 * m1;
+        if (var < 0.f) var = 0.f;
+        const float is = rsqrtf(var + f.eps);
+        smu[threadIdx.x] = mu;
+        sis[threadIdx.x] = is;
+        if (blockIdx.y == 0) {
+            f.mean[c] = mu;
+            f.invstd[c] = is;
+            if (f.run_mean) f.run_mean[c] = (1.f - f.momentum) * f.run_mean[c] + f.momentum * mu;
+            if (f.run_var) {
+                const float unbiased = R > 1 ? var * ((float)R / (float)(R - 1)) : var;
+                f.run_var[c] = (1.f - f.momentum) * f.run_var[c] + f.momentum * unbiased;
+            }
+            if (f.ss_out) {
+                const float sc = gamma[c] * is;
+                f.ss_out[2 * c] = sc;
+                f.ss_out[2 * c + 1] = fmaf(-mu, sc, beta[c]);
+            }
+        }
+    }
+    __syncthreads();
+    const int c = c0 + cl * 4;
+    if (c >= C) return;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(smu + cl * 4), is = *reinterpret_cast<const f32x4*>(sis + cl * 4);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+    while (r < r1) {
+        f32x4 o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float t = fmaf((v[j][k] - mu[k]) * is[k], ga[k], be[k]);      // the expression every mask recomputation uses
+                if (RES) t += rr[j][k];
+                if (RELU) t = fmaxf(t, 0.f);
+                o[j][k] = t;
+            }
+        const long rn = r + 64;
+        if (rn < r1) {        // next rows in flight before this batch is stored
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long off = min(rn + 16 * j, r1 - 1) * C + c;
+                v[j] = *reinterpret_cast<const f32x4*>(z + off);
+                if (RES) rr[j] = *reinterpret_cast<const f32x4*>(res + off);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (r + 16 * j < r1) *reinterpret_cast<f32x4*>(y + (r + 16 * j) * C + c) = o[j];
+        r = rn;
+    }
+}
+
+// statistics only (a BatchNorm whose consumer normalises on load: bn2 in front of conv3's prologue; the stem)
+__global__ __launch_bounds__(256) void bn_finalize_t_kernel(long R, int C, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, BnFin f) {
+    __shared__ float st[2][64];
+    const int c0 = blockIdx.x * 64;
+    reduce_partials_t(f.partial, C, f.ldp, f.nchunk, c0, st);
+    if (threadIdx.x >= 64 || c0 + threadIdx.x >= C) return;
+    const int c = c0 + threadIdx.x;
+    const float inv_n = 1.f / (float)R;
+    const float m1 = st[0][threadIdx.x] * inv_n;
+    const float mu = (f.shift ? f.shift[c] : 0.f) + m1;
+    float var = st[1][threadIdx.x] * inv_n - m1 * m1;
+    if (var < 0.f) var = 0.f;
+    const float is = rsqrtf(var + f.eps);
+    f.mean[c] = mu;
+    f.invstd[c] = is;
+    if (f.run_mean) f.run_mean[c] = (1.f - f.momentum) * f.run_mean[c] + f.momentum * mu;
+    if (f.run_var) {
+        const float unbiased = R > 1 ? var * ((float)R / (float)(R - 1)) : var;
+        f.run_var[c] = (1.f - f.momentum) * f.run_var[c] + f.momentum * unbiased;
+    }
+    if (f.ss_out) {
+        const float sc = gamma[c] * is;
+        f.ss_out[2 * c] = sc;
+        f.ss_out[2 * c + 1] = fmaf(-mu, sc, beta[c]);
+    }
+}
+
+// dz = gamma*invstd*(g - dbeta/R - xhat*dgamma/R) from an already masked g, with dbeta = sum g and dgamma = sum g*xhat
+// summed here from the channel-major partials the mask pass / the reduce pass wrote
+__global__ __launch_bounds__(256) void bn_bwd_dx_fin_kernel(long R, int C, int rows_per_chunk, const float* __restrict__ g,
+                                                            const float* __restrict__ z, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                            const float* __restrict__ partial, int ldp, int nchunk,
+                                                            float* __restrict__ dbeta, float* __restrict__ dgamma,
+                                                            float* __restrict__ dz) {
+    __shared__ float st[2][64];
+    const int c0 = blockIdx.x * 64;
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4, c = c0 + cl * 4, cq = min(c, C - 4);
+    const long r0 = (long)blockIdx.y * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+    f32x4 gg[4], zz[4];       // first rows in flight while the partials are summed
+    long r = r0 + rl;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long off = min(r + 16 * j, r1 - 1) * C + cq;
+        gg[j] = *reinterpret_cast<const f32x4*>(g + off);
+        zz[j] = *reinterpret_cast<const f32x4*>(z + off);
+    }
+    reduce_partials_t(partial, C, ldp, nchunk, c0, st);
+    if (blockIdx.y == 0 && threadIdx.x < 64 && c0 + threadIdx.x < C) {
+        dbeta[c0 + threadIdx.x] = st[0][threadIdx.x];
+        dgamma[c0 + threadIdx.x] = st[1][threadIdx.x];
+    }
+    if (c >= C) return;
+    const float inv_n = 1.f / (float)R;
+    const f32x4 db = *reinterpret_cast<const f32x4*>(&st[0][cl * 4]), dg = *reinterpret_cast<const f32x4*>(&st[1][cl * 4]);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
+    while (r < r1) {
+        f32x4 o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float xh = (zz[j][k] - mu[k]) * is[k];
+                o[j][k] = ga[k] * is[k] * (gg[j][k] - db[k] * inv_n - xh * dg[k] * inv_n);
+            }
+        const long rn = r + 64;
+        if (rn < r1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long off = min(rn + 16 * j, r1 - 1) * C + c;
+                gg[j] = *reinterpret_cast<const f32x4*>(g + off);
+                zz[j] = *reinterpret_cast<const f32x4*>(z + off);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (r + 16 * j < r1) *reinterpret_cast<f32x4*>(dz + (r + 16 * j) * C + c) = o[j];      // dz may alias g: same element, read first
+        r = rn;
     }
 }
 
@@ -371,24 +546,6 @@ inline unsigned ew_blocks(long n4) {
 
 int bn_max_chunks() { return 256; }
 
-int bn_finalize(hipStream_t st, long R, int C, int nchunk, const float* partial, const float* shift, float eps,
-                float momentum, float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma,
-                const float* beta, float* ss_out) {
-    SCN_ARG(R > 0 && C > 0 && nchunk > 0 && partial && mean && invstd, "bn_finalize: bad argument");
-    SCN_ARG(!ss_out || (gamma && beta), "bn_finalize: folded scale/shift need gamma and beta");
-    hipLaunchKernelGGL(bn_finalize_shift_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, R, C, nchunk, partial, shift, eps,
-                       momentum, mean, invstd, run_mean, run_var, gamma, beta, ss_out);
-    SCN_LAUNCH_CHECK();
-    return 0;
-}
-
-int bn_bwd_finalize(hipStream_t st, int C, int nchunk, const float* partial, float* dbeta, float* dgamma) {
-    SCN_ARG(C > 0 && nchunk > 0 && partial && dbeta && dgamma, "bn_bwd_finalize: bad argument");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, C, nchunk, partial, dbeta, dgamma);
-    SCN_LAUNCH_CHECK();
-    return 0;
-}
-
 template <typename T>
 static int bn_stats_t(hipStream_t st, int R, int C, const T* x, float eps, float momentum, float* partial, float* mean,
                       float* invstd, float* run_mean, float* run_var, const float* gamma, const float* beta, float* ss_out) {
@@ -410,18 +567,6 @@ int bn_stats(hipStream_t st, int R, int C, const void* x, int bf16, float eps, f
     SCN_ARG(!ss_out || (gamma && beta), "bn_stats: folded scale/shift need gamma and beta");
     if (bf16) return bn_stats_t<__bf16>(st, R, C, (const __bf16*)x, eps, momentum, partial, mean, invstd, run_mean, run_var, gamma, beta, ss_out);
     return bn_stats_t<float>(st, R, C, (const float*)x, eps, momentum, partial, mean, invstd, run_mean, run_var, gamma, beta, ss_out);
-}
-
-// dz = gamma*invstd*(g - dbeta/R - xhat*dgamma/R) from an ALREADY masked g (the dgrad mask epilogue of cgemm.hip wrote it
-// and its two column sums): the element-wise half of the BatchNorm backward alone
-int bn_bwd_dx(hipStream_t st, int R, int C, const float* g, const float* z, const float* mean, const float* invstd,
-              const float* gamma, const float* dbeta, const float* dgamma, float* dz) {
-    SCN_ARG(R > 0 && C > 0 && C % 4 == 0 && g && z && mean && invstd && gamma && dbeta && dgamma && dz, "bn_bwd_dx: bad argument");
-    const long n4 = (long)R * C / 4;
-    hipLaunchKernelGGL((bn_bwd_dx_kernel<float, false, true, false>), dim3(ew_blocks(n4)), dim3(256), 0, st, n4, R, C, g,
-                       (const float*)nullptr, z, mean, invstd, gamma, (const float*)nullptr, dbeta, dgamma, dz, (float*)nullptr);
-    SCN_LAUNCH_CHECK();
-    return 0;
 }
 
 template <typename T>
@@ -485,6 +630,83 @@ static int bn_bwd_t(hipStream_t st, int R, int C, const T* dy, const T* y, const
 #undef SCN_BN_DX
         SCN_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+// ---- finalize-on-load entry points (fp32 maps, channel-major partials) -----------------------------------------------------
+static inline int ew_chunks(long R, int C, int* rows_per_chunk) {       // ~1024 workgroups, >= 128 rows each: the finalize
+    const int colgroups = cdiv(C, 64);                                    // prologue is paid once per workgroup
+    long n = 1024 / colgroups;
+    const long maxn = (R + 127) / 128;
+    if (n > maxn) n = maxn;
+    if (n < 1) n = 1;
+    long rpc = (R + n - 1) / n;
+    rpc = (rpc + 15) & ~15L;
+    *rows_per_chunk = (int)rpc;
+    return (int)((R + rpc - 1) / rpc);
+}
+
+int bn_apply_fin(hipStream_t st, long R, int C, const float* z, const float* res, const float* partial, int ldp, int nchunk,
+                 const float* shift, float eps, float momentum, const float* gamma, const float* beta, int relu, float* y,
+                 float* mean, float* invstd, float* run_mean, float* run_var, float* ss_out) {
+    SCN_ARG(R > 0 && C > 0 && C % 4 == 0 && z && y && partial && ldp >= nchunk && ldp % 4 == 0 && nchunk > 0 && gamma && beta &&
+            mean && invstd && aligned16(z) && aligned16(y) && aligned16(partial) && (!res || aligned16(res)), "bn_apply_fin: bad argument");
+    SCN_ARG(shift != run_mean || !run_mean, "bn_apply_fin: shift must not alias the running mean it updates");
+    SCN_ARG(2L * C * ldp * 4 < 0x7fffffffL, "bn_apply_fin: partial too large");
+    BnFin f{partial, ldp, nchunk, shift, eps, momentum, mean, invstd, run_mean, run_var, ss_out};
+    int rpc;
+    const int nch = ew_chunks(R, C, &rpc);
+    dim3 grid(cdiv(C, 64), nch), block(256);
+    if (relu && res)  hipLaunchKernelGGL((bn_apply_fin_kernel<true, true>), grid, block, 0, st, R, C, rpc, z, res, gamma, beta, y, f);
+    else if (relu)    hipLaunchKernelGGL((bn_apply_fin_kernel<true, false>), grid, block, 0, st, R, C, rpc, z, res, gamma, beta, y, f);
+    else if (res)     hipLaunchKernelGGL((bn_apply_fin_kernel<false, true>), grid, block, 0, st, R, C, rpc, z, res, gamma, beta, y, f);
+    else              hipLaunchKernelGGL((bn_apply_fin_kernel<false, false>), grid, block, 0, st, R, C, rpc, z, res, gamma, beta, y, f);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
+int bn_finalize_t(hipStream_t st, long R, int C, const float* partial, int ldp, int nchunk, const float* shift, float eps,
+                  float momentum, float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma,
+                  const float* beta, float* ss_out) {
+    SCN_ARG(R > 0 && C > 0 && partial && ldp >= nchunk && ldp % 4 == 0 && nchunk > 0 && mean && invstd && aligned16(partial),
+            "bn_finalize_t: bad argument");
+    SCN_ARG(!ss_out || (gamma && beta), "bn_finalize_t: folded scale/shift need gamma and beta");
+    SCN_ARG(2L * C * ldp * 4 < 0x7fffffffL, "bn_finalize_t: partial too large");
+    BnFin f{partial, ldp, nchunk, shift, eps, momentum, mean, invstd, run_mean, run_var, ss_out};
+    hipLaunchKernelGGL(bn_finalize_t_kernel, dim3(cdiv(C, 64)), dim3(256), 0, st, R, C, gamma, beta, f);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
+// g = dy * [y > 0] (relu with the forward output y) or dy; sums of g and g*xhat as channel-major partials [2][C][ldp];
+// g is written to gout (it is the residual branch's gradient).  Returns the chunk count through nchunk_out.
+int bn_bwd_reduce_t(hipStream_t st, int R, int C, const float* dy, const float* y, const float* z, const float* mean,
+                    const float* invstd, int relu, float* partial, int ldp_cap, float* gout, int* nchunk_out) {
+    SCN_ARG(R > 0 && C > 0 && C % 4 == 0 && dy && z && mean && invstd && partial && (!relu || y), "bn_bwd_reduce_t: bad argument");
+    int rpc;
+    const int nchunk = pick_chunks(R, C, &rpc);
+    const int ldp = (nchunk + 3) & ~3;
+    SCN_ARG(ldp <= ldp_cap, "bn_bwd_reduce_t: partial buffer too small");
+    dim3 grid(cdiv(C, 64), nchunk), block(256);
+    const float* nf = nullptr;
+    if (relu && gout) hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, true, false, true>), grid, block, 0, st, R, C, rpc, dy, y, z, mean, invstd, nf, nf, partial, gout, ldp);
+    else if (relu)    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, true, false, false>), grid, block, 0, st, R, C, rpc, dy, y, z, mean, invstd, nf, nf, partial, (float*)nullptr, ldp);
+    else              hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, false, false, false>), grid, block, 0, st, R, C, rpc, dy, y, z, mean, invstd, nf, nf, partial, (float*)nullptr, ldp);
+    SCN_LAUNCH_CHECK();
+    if (nchunk_out) *nchunk_out = nchunk;
+    return 0;
+}
+
+int bn_bwd_dx_fin(hipStream_t st, long R, int C, const float* g, const float* z, const float* mean, const float* invstd,
+                  const float* gamma, const float* partial, int ldp, int nchunk, float* dbeta, float* dgamma, float* dz) {
+    SCN_ARG(R > 0 && C > 0 && C % 4 == 0 && g && z && mean && invstd && gamma && partial && ldp >= nchunk && ldp % 4 == 0 &&
+            nchunk > 0 && dbeta && dgamma && dz && aligned16(g) && aligned16(z) && aligned16(dz) && aligned16(partial), "bn_bwd_dx_fin: bad argument");
+    SCN_ARG(2L * C * ldp * 4 < 0x7fffffffL, "bn_bwd_dx_fin: partial too large");
+    int rpc;
+    const int nch = ew_chunks(R, C, &rpc);
+    hipLaunchKernelGGL(bn_bwd_dx_fin_kernel, dim3(cdiv(C, 64), nch), dim3(256), 0, st, R, C, rpc, g, z, mean, invstd, gamma, partial,
+                       ldp, nchunk, dbeta, dgamma, dz);
+    SCN_LAUNCH_CHECK();
     return 0;
 }
 

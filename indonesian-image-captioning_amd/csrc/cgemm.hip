@@ -39,6 +39,8 @@
 
 namespace scn {
 
+int cgemm_stat_ld(int M);
+
 namespace {
 
 constexpr int TN = 128, TK = 16, NSTAGE = 3;
@@ -65,7 +67,8 @@ struct CArgs {
     long src_rows;                // 3x3 modes: rows of the gathered map (N * gHi * gWi)
     int dHi, dWi;                 // mode 4: extent of the d-input map the rows are scattered into
     const float* pro_ss;          // interleaved {scale, shift} per channel: PRO 1 per k (A), PRO 2 per n (B)
-    float* stat_partial; const float* stat_shift;       // [cdiv(M, 64)][2][N]
+    float* stat_partial; const float* stat_shift;       // [2][N][ldp]: channel-major, one entry per 64-row block (chunk)
+    int ldp;                      // leading dimension of stat_partial: cdiv(M, 64) rounded up to 4 (cgemm_stat_ld)
     const float* ez; const float* emean; const float* einvstd; const float* egamma; const float* ebeta;  // mask pass
     long ldz;
 };
@@ -528,9 +531,9 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
             s2 += __shfl_xor(s2, 32, 64);
             if (MI == 2) {
                 if (lane < 32 && n < g.N && mw0 < g.M) {
-                    float* p = g.stat_partial + ((long)(tm * 2 + wm) * 2) * g.N + n;
+                    float* p = g.stat_partial + (long)n * g.ldp + (tm * 2 + wm);
                     p[0] = s1;
-                    p[g.N] = s2;
+                    p[(long)g.N * g.ldp] = s2;
                 }
             } else if (lane < 32) {
                 colsum[(wm * 2 + 0) * TN + wn * 64 + j * 32 + l31] = s1;
@@ -541,9 +544,9 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (tid < TN && n0 + tid < g.N) {
-                float* p = g.stat_partial + ((long)tm * 2) * g.N + n0 + tid;
+                float* p = g.stat_partial + (long)(n0 + tid) * g.ldp + tm;
                 p[0] = colsum[0 * TN + tid] + colsum[2 * TN + tid];
-                p[g.N] = colsum[1 * TN + tid] + colsum[3 * TN + tid];
+                p[(long)g.N * g.ldp] = colsum[1 * TN + tid] + colsum[3 * TN + tid];
             }
         }
         if (W41) {     // waves (0,1) form the tile's first 64-row statistics block, waves (2,3) its second
@@ -551,9 +554,9 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
             __builtin_amdgcn_s_barrier();
             const int blk = tid >> 6, col = tid & 63;
             if (tid < 128 && n0 + col < g.N && m0 + blk * 64 < g.M) {
-                float* p = g.stat_partial + ((long)(tm * 2 + blk) * 2) * g.N + n0 + col;
+                float* p = g.stat_partial + (long)(n0 + col) * g.ldp + (tm * 2 + blk);
                 p[0] = colsum[((2 * blk) * 2 + 0) * TN + col] + colsum[((2 * blk + 1) * 2 + 0) * TN + col];
-                p[g.N] = colsum[((2 * blk) * 2 + 1) * TN + col] + colsum[((2 * blk + 1) * 2 + 1) * TN + col];
+                p[(long)g.N * g.ldp] = colsum[((2 * blk) * 2 + 1) * TN + col] + colsum[((2 * blk + 1) * 2 + 1) * TN + col];
             }
         }
 #pragma unroll
@@ -747,7 +750,7 @@ __global__ __launch_bounds__(256) void cstats_kernel(CArgs g) {
             float t = red[0][which][cc];
 #pragma unroll
             for (int i = 1; i < 16; ++i) t += red[i][which][cc];
-            g.stat_partial[((long)blockIdx.y * 2 + which) * g.N + blockIdx.x * 64 + cc] = t;
+            g.stat_partial[((long)which * g.N + blockIdx.x * 64 + cc) * g.ldp + blockIdx.y] = t;
         }
     }
 }
@@ -918,7 +921,7 @@ int cgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
         g.c3c = ex->c3c; g.src_rows = ex->c3_src_rows;
         if (c3 == 4) { g.gHi = ex->Ho; g.gWi = ex->Wo; g.dHi = ex->Hi; g.dWi = ex->Wi; }   // gathered map = dY (Ho x Wo)
         g.pro_ss = ex->pro_ss;
-        g.stat_partial = ex->stat_partial; g.stat_shift = ex->stat_shift;
+        g.stat_partial = ex->stat_partial; g.stat_shift = ex->stat_shift; g.ldp = cgemm_stat_ld(M);
         g.ez = ex->ez; g.emean = ex->emean; g.einvstd = ex->einvstd; g.egamma = ex->egamma; g.ebeta = ex->ebeta; g.ldz = ex->ldz;
     }
     dim3 grid(mt * nt, c3 == 4 ? 4 : batch * S), block(256);
@@ -949,6 +952,10 @@ int cgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
 }
 
 int cgemm_row_tiles(int M) { return cdiv(M, SROWS); }
+// Statistics partials are CHANNEL-MAJOR, [2][N][cgemm_stat_ld(M)]: entry (which, channel, 64-row block).  A consumer that
+// needs the sums of a few channels (BatchNorm apply / backward kernels that finalize on load, csrc/batchnorm.hip) reads
+// contiguous rows instead of a strided column.
+int cgemm_stat_ld(int M) { return (cdiv(M, SROWS) + 3) & ~3; }
 
 // C[M][N] (leading dimension ldc) = sum of S slabs [S][M][N] in slab order: the split-K reducer on its own, for kernels
 // outside this file that write the same slab layout (csrc/conv3.hip).

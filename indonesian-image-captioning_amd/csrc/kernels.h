@@ -24,7 +24,7 @@ struct ConvExtra {
     int pro = 0;              // 1: A = relu(A*scale[k]+shift[k]) (k-contiguous A); 2: B = relu(B*scale[n]+shift[n]) ([K][N] B)
     int epi = 0;              // 1: column sums of (y-s), (y-s)^2 per 64 rows; 2: relu mask from z + sums of g, g*xhat
     const float* pro_ss = nullptr;    // interleaved {scale, shift} per channel
-    float* stat_partial = nullptr;    // [row tiles][2][N]
+    float* stat_partial = nullptr;    // [2][N][cgemm_stat_ld(M)], channel-major
     const float* stat_shift = nullptr;
     const float* ez = nullptr; const float* emean = nullptr; const float* einvstd = nullptr;
     const float* egamma = nullptr; const float* ebeta = nullptr; long ldz = 0;
@@ -41,6 +41,7 @@ int cgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
           long ldb, float beta, float* C, long ldc, const float* bias, const float* rowmask, int batch, long sA, long sB,
           long sC, float* ws, long ws_floats, const ConvExtra* ex);
 int cgemm_row_tiles(int M);
+int cgemm_stat_ld(int M);      // leading dimension of the channel-major statistics partial [2][N][ld] a product of M rows writes
 int cgemm_reduce(hipStream_t st, const float* ws, int S, int M, int N, float* C, long ldc);
 
 // ---- conv3.hip: 3x3 weight gradient (stride 1) with the activation halo staged once per strip ---------------------
@@ -176,18 +177,22 @@ int bn_max_chunks();
 int bn_stats(hipStream_t st, int R, int C, const void* x, int bf16, float eps, float momentum, float* partial,
              float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma = nullptr,
              const float* beta = nullptr, float* ss_out = nullptr);
-int bn_bwd_dx(hipStream_t st, int R, int C, const float* g, const float* z, const float* mean, const float* invstd,
-              const float* gamma, const float* dbeta, const float* dgamma, float* dz);
 int bn_apply(hipStream_t st, int R, int C, const void* z, const void* res, int bf16, const float* mean,
              const float* invstd, const float* gamma, const float* beta, int relu, void* y);
 int bn_bwd(hipStream_t st, int R, int C, const void* dy, const void* y, const void* z, int bf16, const float* mean,
            const float* invstd, const float* gamma, const float* beta, int relu, int train, float* partial, float* dbeta,
            float* dgamma, void* dz, void* dres);
 
-// statistics from partial[nchunk][2][C] (the GEMM epilogues of cgemm.hip), any nchunk
-int bn_finalize(hipStream_t st, long R, int C, int nchunk, const float* partial, const float* shift, float eps,
-                float momentum, float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma,
-                const float* beta, float* ss_out);
-int bn_bwd_finalize(hipStream_t st, int C, int nchunk, const float* partial, float* dbeta, float* dgamma);
+// ---- finalize on load: channel-major partials [2][C][ldp] (cgemm statistics epilogues, cstats, bn_bwd_reduce_t, the stem) ----
+int bn_finalize_t(hipStream_t st, long R, int C, const float* partial, int ldp, int nchunk, const float* shift, float eps,
+                  float momentum, float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma,
+                  const float* beta, float* ss_out);
+int bn_apply_fin(hipStream_t st, long R, int C, const float* z, const float* res, const float* partial, int ldp, int nchunk,
+                 const float* shift, float eps, float momentum, const float* gamma, const float* beta, int relu, float* y,
+                 float* mean, float* invstd, float* run_mean, float* run_var, float* ss_out);
+int bn_bwd_reduce_t(hipStream_t st, int R, int C, const float* dy, const float* y, const float* z, const float* mean,
+                    const float* invstd, int relu, float* partial, int ldp_cap, float* gout, int* nchunk_out);
+int bn_bwd_dx_fin(hipStream_t st, long R, int C, const float* g, const float* z, const float* mean, const float* invstd,
+                  const float* gamma, const float* partial, int ldp, int nchunk, float* dbeta, float* dgamma, float* dz);
 
 }  // namespace scn

@@ -37,8 +37,8 @@ struct StemArgs {
     const float* x; long sn, sc, sh, sw; long x_elems;   // element strides of the (N,3,H,W) input, whatever its memory format
     const float* w; long wn, wc, wh, ww;                 // element strides of the (64,3,7,7) weight
     float* z;                                            // [N*Ho*Wo][64]
-    float* partial; const float* stat_shift;             // [workgroups][2][64]; partial == nullptr: no statistics
-    int N, H, W, Ho, Wo, tx, ty, ntiles;
+    float* partial; const float* stat_shift;             // channel-major [2][64][ldp], one entry per workgroup; nullptr: no statistics
+    int N, H, W, Ho, Wo, tx, ty, ntiles, ldp;
 };
 
 __global__ __launch_bounds__(256, 3) void stem_conv7_kernel(StemArgs g) {
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, 3) void stem_conv7_kernel(StemArgs g) {
         }
     }
     // one partial row per (persistent) workgroup, tiles summed in the order this workgroup walked them
-    if (g.partial && tid < 128) g.partial[((long)blockIdx.x * 2 + (tid >> 6)) * 64 + (tid & 63)] = stat_run;
+    if (g.partial && tid < 128) g.partial[((long)(tid >> 6) * 64 + (tid & 63)) * g.ldp + blockIdx.x] = stat_run;   // channel-major [2][64][ldp]
 }
 
 // out[(n,oh,ow)][c] = max over the 3x3 / stride 2 / padding 1 window of relu(z*scale[c] + shift[c]); 4 channels per thread
@@ -190,7 +190,7 @@ int stem_tiles(int N, int H, int W) {
 }
 
 // x: (N,3,H,W) with element strides (sn,sc,sh,sw); w: (64,3,7,7) with element strides (wn,wc,wh,ww);
-// z [N*Ho*Wo][64], Ho = (H-1)/2+1; partial [stem_tiles(N,H,W)][2][64] or NULL.
+// z [N*Ho*Wo][64], Ho = (H-1)/2+1; partial [2][64][(stem_tiles(N,H,W) + 3) & ~3] (channel-major, as csrc/cgemm.hip writes them) or NULL.
 int stem_conv7(hipStream_t st, int N, int H, int W, const float* x, long sn, long sc, long sh, long sw, const float* w,
                long wn, long wc, long wh, long ww, float* z, float* partial, const float* stat_shift) {
     SCN_ARG(N > 0 && H > 0 && W > 0 && x && w && z, "stem_conv7: arguments");
@@ -203,6 +203,7 @@ int stem_conv7(hipStream_t st, int N, int H, int W, const float* x, long sn, lon
     g.N = N; g.H = H; g.W = W; g.Ho = (H - 1) / 2 + 1; g.Wo = (W - 1) / 2 + 1;
     g.ty = cdiv(g.Ho, S_TH); g.tx = cdiv(g.Wo, S_TW); g.ntiles = N * g.tx * g.ty;
     const int grid = g.ntiles < 768 ? g.ntiles : 768;      // persistent: 3 workgroups per CU keep the weights in LDS
+    g.ldp = (grid + 3) & ~3;
     hipLaunchKernelGGL(stem_conv7_kernel, dim3(grid), dim3(256), 0, st, g);
     SCN_LAUNCH_CHECK();
     return 0;

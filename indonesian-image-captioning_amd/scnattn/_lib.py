@@ -53,17 +53,6 @@ class ConvExtra(C.Structure):      # scnattn_conv_extra
                 ("force_split", C.c_int), ("force_mi", C.c_int)]
 
 
-class Block(C.Structure):          # scnattn_block
-    _fields_ = [(n, C.c_int) for n in ("N", "Hi", "Wi", "Cin", "P", "stride", "has_down")] + \
-               [(n, C.c_float) for n in ("eps1", "mom1", "eps2", "mom2", "eps3", "mom3", "epsd", "momd")] + \
-               [(n, C.c_void_p) for n in ("w1", "g1", "b1", "w2", "g2", "b2", "w3", "g3", "b3", "wd", "gd", "bd",
-                                          "rm1", "rv1", "rm2", "rv2", "rm3", "rv3", "rmd", "rvd")]
-
-
-class BlockGrads(C.Structure):     # scnattn_block_grads
-    _fields_ = [("dw1", C.c_void_p), ("dw3", C.c_void_p)]
-
-
 _SIGS = {
     "scnattn_version": ([], i32),
     "scnattn_set_option": ([C.c_char_p, i32], i32),
@@ -88,16 +77,15 @@ _SIGS = {
     "scnattn_conv3x3_dgrad": ([vp, i32, i32, i32, i32, i32, vp, vp, vp, C.POINTER(ConvExtra), vp, i64], i32),
     "scnattn_conv3x3_wgrad": ([vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i64, i32], i32),
     "scnattn_conv3x3_dgrad_strided": ([vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i64], i32),
+    "scnattn_cgemm_stat_ld": ([i32], i32),
+    "scnattn_bn_finalize": ([vp, i64, i32, vp, i32, i32, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp], i32),
+    "scnattn_bn_apply_fin": ([vp, i64, i32, vp, vp, vp, i32, i32, vp, f32, f32, vp, vp, i32, vp, vp, vp, vp, vp, vp], i32),
+    "scnattn_bn_bwd_reduce": ([vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, C.POINTER(C.c_int)], i32),
+    "scnattn_bn_bwd_dx_fin": ([vp, i64, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp], i32),
     "scnattn_stem_tiles": ([i32, i32, i32], i32),
     "scnattn_stem_conv7": ([vp, i32, i32, i32, vp, i64, i64, i64, i64, vp, i64, i64, i64, i64, vp, vp, vp], i32),
     "scnattn_stem_bn_relu_maxpool": ([vp, i32, i32, i32, i32, vp, vp, vp], i32),
-    "scnattn_block_sizes": ([C.POINTER(Block), C.POINTER(sz), C.POINTER(sz), C.POINTER(C.c_long)], i32),
-    "scnattn_block_fwd": ([vp, C.POINTER(Block), vp, vp, vp, vp, i64, vp, vp], i32),
-    "scnattn_block_bwd": ([vp, vp, C.POINTER(Block), vp, vp, vp, vp, vp, vp, C.POINTER(BlockGrads), vp, vp, i64, vp, vp, i32], i32),
-    "scnattn_bn_finalize": ([vp, i64, i32, i32, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp], i32),
-    "scnattn_bn_bwd_finalize": ([vp, i32, i32, vp, vp, vp], i32),
     "scnattn_bn_stats_fold": ([vp, i32, i32, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp], i32),
-    "scnattn_bn_bwd_dx": ([vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp], i32),
     "scnattn_skinny_gemm": ([vp, i32, i32, i32, i32, vp, i64, i64, vp, i64, i64, vp, i64, i64, i64, i32,
                              C.POINTER(i32)], i32),
     "scnattn_skinny_gemm_bf16w": ([vp, i32, i32, i32, i32, vp, i64, i64, vp, i64, i64, vp, i64, i64, i64, i32,

@@ -232,17 +232,62 @@ def _conv_fwd(h, st, x2, w2, R, Cin, Cout, ws, ex):
     return y
 
 
-def _finalize(h, st, R, Cn, part, bn_mod, training, gamma, beta, want_ss):
+def _shift(bn):
+    """Conditioning shift s for the sums of (z - s), (z - s)^2 a statistics epilogue takes: the PREVIOUS step's batch mean
+    of this BatchNorm (the running mean before the first step).  Any vector works mathematically; it must not be the
+    running mean itself, because the kernel that finalizes the statistics updates that in place while workgroups that
+    started later still read the shift (include/scnattn.h: scnattn_bn_apply_fin)."""
+    s = getattr(bn, "_scn_shift", None)
+    if s is None or s.device != bn.running_mean.device or s.shape != bn.running_mean.shape:
+        s = bn.running_mean.detach().clone()
+    return s
+
+
+def _finalize(h, st, R, Cn, part, bn_mod, shift, gamma, beta, want_ss):
+    """Statistics only (the consumer normalises on load): mean / invstd / running statistics / folded {scale, shift}."""
     dev = part.device
     stats = torch.empty((2, Cn), device=dev, dtype=torch.float32)
     ss = torch.empty((Cn, 2), device=dev, dtype=torch.float32) if want_ss else None
-    mt = h.scnattn_cgemm_row_tiles(R)
-    _chk(h.scnattn_bn_finalize(st, R, Cn, mt, part.data_ptr(), bn_mod.running_mean.data_ptr(), bn_mod.eps,
-                               bn_mod.momentum, stats[0].data_ptr(), stats[1].data_ptr(),
+    _chk(h.scnattn_bn_finalize(st, R, Cn, part.data_ptr(), h.scnattn_cgemm_stat_ld(R), h.scnattn_cgemm_row_tiles(R),
+                               shift.data_ptr(), bn_mod.eps, bn_mod.momentum, stats[0].data_ptr(), stats[1].data_ptr(),
                                bn_mod.running_mean.data_ptr(), bn_mod.running_var.data_ptr(),
                                gamma.data_ptr() if want_ss else None, beta.data_ptr() if want_ss else None,
                                ss.data_ptr() if want_ss else None), "scnattn_bn_finalize")
+    bn_mod._scn_shift = stats[0]
     return stats, ss
+
+
+def _apply_fin(h, st, R, Cn, z, res, part, bn_mod, shift, gamma, beta, relu):
+    """y = [relu](bn(z) [+ res]) with the statistics finalized inside the same launch (csrc/batchnorm.hip)."""
+    stats = torch.empty((2, Cn), device=z.device, dtype=torch.float32)
+    y = torch.empty_like(z)
+    _chk(h.scnattn_bn_apply_fin(st, R, Cn, z.data_ptr(), None if res is None else res.data_ptr(), part.data_ptr(),
+                                h.scnattn_cgemm_stat_ld(R), h.scnattn_cgemm_row_tiles(R), shift.data_ptr(), bn_mod.eps,
+                                bn_mod.momentum, gamma.data_ptr(), beta.data_ptr(), 1 if relu else 0, y.data_ptr(),
+                                stats[0].data_ptr(), stats[1].data_ptr(), bn_mod.running_mean.data_ptr(),
+                                bn_mod.running_var.data_ptr(), None), "scnattn_bn_apply_fin")
+    bn_mod._scn_shift = stats[0]
+    return y, stats
+
+
+def _bwd_reduce(h, st, R, Cn, dy, y, z, stats, relu, bnpart, want_g):
+    """BatchNorm(+ReLU) backward, first half: g = dy * [y > 0] (or dy) and the channel-major partial sums of g, g*xhat."""
+    g = torch.empty((R, Cn), device=dy.device, dtype=torch.float32) if want_g else None
+    nch = C.c_int(0)
+    _chk(h.scnattn_bn_bwd_reduce(st, R, Cn, dy.data_ptr(), None if y is None else y.data_ptr(), z.data_ptr(),
+                                 stats[0].data_ptr(), stats[1].data_ptr(), 1 if relu else 0, bnpart.data_ptr(),
+                                 bnpart.numel() // (2 * Cn), None if g is None else g.data_ptr(), C.byref(nch)),
+         "scnattn_bn_bwd_reduce")
+    return g, nch.value
+
+
+def _bwd_dx_fin(h, st, R, Cn, g, z, stats, gamma, partial, ldp, nchunk, dz):
+    """Second half: d beta / d gamma summed from the partials and dz, one launch; dz may alias g."""
+    dgb = torch.empty((2, Cn), device=g.device, dtype=torch.float32)
+    _chk(h.scnattn_bn_bwd_dx_fin(st, R, Cn, g.data_ptr(), z.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
+                                 gamma.data_ptr(), partial.data_ptr(), ldp, nchunk, dgb[0].data_ptr(), dgb[1].data_ptr(),
+                                 dz.data_ptr()), "scnattn_bn_bwd_dx_fin")
+    return dgb
 
 
 def _grad_out(w):
@@ -288,23 +333,21 @@ class _BottleneckFn(torch.autograd.Function):
         Rin, Rout = N * Hi * Wi, N * Ho * Wo
         x2 = _as2d(x)
         bn1, bn2, bn3 = mod.bn1, mod.bn2, mod.bn3
-        # conv1 (+ bn1 statistics)
-        ex = ConvExtra(epi=1, stat_partial=part.data_ptr(), stat_shift=bn1.running_mean.data_ptr())
+        # conv1 (+ bn1 statistics) -> bn1 apply + relu with the finalize inside
+        sh1 = _shift(bn1)
+        ex = ConvExtra(epi=1, stat_partial=part.data_ptr(), stat_shift=sh1.data_ptr())
         z1 = _conv_fwd(h, st, x2, w1.view(p, Cin), Rin, Cin, p, ws, ex)
-        st1, _ = _finalize(h, st, Rin, p, part, bn1, True, g1, b1, False)
-        a1 = torch.empty_like(z1)
-        _chk(h.scnattn_bn_apply(st, Rin, p, z1.data_ptr(), None, 0, st1[0].data_ptr(), st1[1].data_ptr(), g1.data_ptr(),
-                                b1.data_ptr(), 1, a1.data_ptr()), "scnattn_bn_apply")
+        a1, st1 = _apply_fin(h, st, Rin, p, z1, None, part, bn1, sh1, g1, b1, True)
         # conv2 (3x3, strided for layerN.0): the implicit-GEMM mode of the same kernel with the bn2 statistics epilogue
-        a1_4 = _as4d(a1, N, Hi, Wi)
+        sh2 = _shift(bn2)
         if CONV3 == "hip":
             z2 = torch.empty((Rout, p), device=dev, dtype=torch.float32)
-            ex3 = ConvExtra(epi=1, stat_partial=part.data_ptr(), stat_shift=bn2.running_mean.data_ptr())
+            ex3 = ConvExtra(epi=1, stat_partial=part.data_ptr(), stat_shift=sh2.data_ptr())
             _chk(h.scnattn_conv3x3_fwd(st, N, Hi, Wi, p, p, s, a1.data_ptr(), w2.data_ptr(), z2.data_ptr(), C.byref(ex3),
                                        ws.data_ptr(), ws.numel()), "scnattn_conv3x3_fwd")
-            st2, ss2 = _finalize(h, st, Rout, p, part, bn2, True, g2, b2, True)
+            st2, ss2 = _finalize(h, st, Rout, p, part, bn2, sh2, g2, b2, True)
         else:       # A/B only: MIOpen + a statistics pass over z2
-            z4 = torch.ops.aten.convolution(a1_4, w2, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1)
+            z4 = torch.ops.aten.convolution(_as4d(a1, N, Hi, Wi), w2, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1)
             if not z4.is_contiguous(memory_format=torch.channels_last):
                 z4 = z4.contiguous(memory_format=torch.channels_last)
             z2 = _as2d(z4)
@@ -314,27 +357,34 @@ class _BottleneckFn(torch.autograd.Function):
                                          st2[0].data_ptr(), st2[1].data_ptr(), bn2.running_mean.data_ptr(),
                                          bn2.running_var.data_ptr(), g2.data_ptr(), b2.data_ptr(), ss2.data_ptr()),
                  "scnattn_bn_stats_fold")
-        # conv3 with the bn2+relu prologue (+ bn3 statistics)
-        ex = ConvExtra(pro=1, epi=1, pro_ss=ss2.data_ptr(), stat_partial=part.data_ptr(),
-                       stat_shift=bn3.running_mean.data_ptr())
+        # conv3 with the bn2+relu prologue (+ bn3 statistics into `part`)
+        sh3 = _shift(bn3)
+        ex = ConvExtra(pro=1, epi=1, pro_ss=ss2.data_ptr(), stat_partial=part.data_ptr(), stat_shift=sh3.data_ptr())
         z3 = _conv_fwd(h, st, z2, w3.view(C4, p), Rout, p, C4, ws, ex)
-        st3, _ = _finalize(h, st, Rout, C4, part, bn3, True, g3, b3, False)
-        # identity
+        # identity (the downsample branch keeps its statistics in the second partial buffer: `part` is still pending)
         zd = std = None
         if wd is not None:
             bnd = mod.downsample[1]
-            ex = ConvExtra(epi=1, stat_partial=part.data_ptr(), stat_shift=bnd.running_mean.data_ptr(),
+            shd = _shift(bnd)
+            ex = ConvExtra(epi=1, stat_partial=bnpart.data_ptr(), stat_shift=shd.data_ptr(),
                            stride=s, Hi=Hi, Wi=Wi, Ho=Ho, Wo=Wo)
             zd = _conv_fwd(h, st, x2, wd.view(C4, Cin), Rout, Cin, C4, ws, ex)
-            std, _ = _finalize(h, st, Rout, C4, part, bnd, True, gd, bd, False)
-            idn = torch.empty_like(zd)
-            _chk(h.scnattn_bn_apply(st, Rout, C4, zd.data_ptr(), None, 0, std[0].data_ptr(), std[1].data_ptr(),
-                                    gd.data_ptr(), bd.data_ptr(), 0, idn.data_ptr()), "scnattn_bn_apply")
+            idn, std = _apply_fin(h, st, Rout, C4, zd, None, bnpart, bnd, shd, gd, bd, False)
         else:
             idn = x2
-        out = torch.empty((Rout, C4), device=dev, dtype=torch.float32)
-        _chk(h.scnattn_bn_apply(st, Rout, C4, z3.data_ptr(), idn.data_ptr(), 0, st3[0].data_ptr(), st3[1].data_ptr(),
-                                g3.data_ptr(), b3.data_ptr(), 1, out.data_ptr()), "scnattn_bn_apply")
+        out, st3 = _apply_fin(h, st, Rout, C4, z3, idn, part, bn3, sh3, g3, b3, True)
+        # conv1's d input wants w1 transposed ([Cin][p]: both operands k-contiguous); the weights do not change between this
+        # forward pass and its backward pass, so the transpose runs NOW on the idle side stream instead of on the backward
+        # pass's critical path
+        wt = wt_ev = None
+        if ctx.needs_input_grad[1] and SIDE_WGRAD:
+            sd = _side(dev)
+            wt = torch.empty((Cin, p), device=dev, dtype=torch.float32)
+            sw = sd.fork(torch.cuda.current_stream(dev), w1, wt)
+            _chk(h.scnattn_transpose2d(sw, p, Cin, w1.data_ptr(), Cin, wt.data_ptr(), p), "scnattn_transpose2d")
+            wt_ev = torch.cuda.Event()
+            wt_ev.record(sd.stream)
+        ctx.wt, ctx.wt_ev = wt, wt_ev
         ctx.geom = (N, Cin, Hi, Wi, p, C4, s, Ho, Wo)
         ctx.has_down = wd is not None
         ctx.save_for_backward(x, w1, g1, b1, w2, g2, b2, w3, g3, b3, wd, gd, bd, z1, a1, z2, z3, out, zd, st1, st2, ss2,
@@ -357,16 +407,13 @@ class _BottleneckFn(torch.autograd.Function):
         dout2 = _as2d(dout)
         x2 = _as2d(x)
         f32 = dict(device=dev, dtype=torch.float32)
-        # ---- bn3 (+ identity + relu) backward: dz3, d identity ------------------------------------------------
+        ld_out, nc_out = h.scnattn_cgemm_stat_ld(Rout), h.scnattn_cgemm_row_tiles(Rout)
+        ld_in, nc_in = h.scnattn_cgemm_stat_ld(Rin), h.scnattn_cgemm_row_tiles(Rin)
+        # ---- bn3 (+ identity + relu) backward: g = dout * [out > 0] = d identity; dz3 ---------------------------------
+        dres, nch = _bwd_reduce(h, st, Rout, C4, dout2, out, z3, st3, True, bnpart, True)
         dz3 = torch.empty((Rout, C4), **f32)
-        need_res = need[1] or ctx.has_down
-        dres = torch.empty((Rout, C4), **f32) if need_res else None
-        dgb3 = torch.empty((2, C4), **f32)
-        _chk(h.scnattn_bn_bwd(st, Rout, C4, dout2.data_ptr(), out.data_ptr(), z3.data_ptr(), 0, st3[0].data_ptr(),
-                              st3[1].data_ptr(), g3.data_ptr(), None, 1, 1, bnpart.data_ptr(), dgb3[0].data_ptr(),
-                              dgb3[1].data_ptr(), dz3.data_ptr(), None if dres is None else dres.data_ptr()),
-             "scnattn_bn_bwd")
-        # ---- conv3: wgrad with a2 recomputed on load, dgrad with the bn2 mask / reduction epilogue ----------------
+        dgb3 = _bwd_dx_fin(h, st, Rout, C4, dres, z3, st3, g3, bnpart, (nch + 3) & ~3, nch, dz3)
+        # ---- conv3: wgrad with a2 recomputed on load, dgrad with the bn2 mask / reduction pass -------------------------
         main = torch.cuda.current_stream(dev)
         side = _side(dev) if side_ok(w1, w2, w3, wd) else None
         dw3 = None
@@ -376,32 +423,30 @@ class _BottleneckFn(torch.autograd.Function):
             sw, wsw = (side.fork(main, dz3, z2, ss2, dw3), side.ws) if side else (st, ws)
             _chk(h.scnattn_conv1x1_wgrad(sw, Rout, p, C4, dz3.data_ptr(), z2.data_ptr(), dw3.data_ptr(), C.byref(ex),
                                          wsw.data_ptr(), wsw.numel()), "scnattn_conv1x1_wgrad")
-        g2m = torch.empty((Rout, p), **f32)
+        dz2 = torch.empty((Rout, p), **f32)        # first the masked d a2, then (in place) dz2
         ex = ConvExtra(epi=2, stat_partial=part.data_ptr(), ez=z2.data_ptr(), emean=st2[0].data_ptr(),
                        einvstd=st2[1].data_ptr(), egamma=g2.data_ptr(), ebeta=b2.data_ptr(), ldz=p,
                        pro_ss=ss2.data_ptr())      # mask = [fma(z2, scale, shift) > 0]: what conv3's prologue evaluated
-        _chk(h.scnattn_conv1x1_dgrad(st, Rout, p, C4, dz3.data_ptr(), w3.data_ptr(), 0, 0.0, g2m.data_ptr(), C.byref(ex),
+        _chk(h.scnattn_conv1x1_dgrad(st, Rout, p, C4, dz3.data_ptr(), w3.data_ptr(), 0, 0.0, dz2.data_ptr(), C.byref(ex),
                                      ws.data_ptr(), ws.numel()), "scnattn_conv1x1_dgrad")
-        dgb2 = torch.empty((2, p), **f32)
-        _chk(h.scnattn_bn_bwd_finalize(st, p, h.scnattn_cgemm_row_tiles(Rout), part.data_ptr(), dgb2[0].data_ptr(),
-                                       dgb2[1].data_ptr()), "scnattn_bn_bwd_finalize")
-        dz2 = torch.empty((Rout, p), **f32)
-        _chk(h.scnattn_bn_bwd_dx(st, Rout, p, g2m.data_ptr(), z2.data_ptr(), st2[0].data_ptr(), st2[1].data_ptr(),
-                                 g2.data_ptr(), dgb2[0].data_ptr(), dgb2[1].data_ptr(), dz2.data_ptr()), "scnattn_bn_bwd_dx")
-        del g2m
-        # ---- conv2: weight gradient (side stream) and d input ------------------------------------------------------------
+        dgb2 = _bwd_dx_fin(h, st, Rout, p, dz2, z2, st2, g2, part, ld_out, nc_out, dz2)
+        # ---- conv2: weight gradient (side stream) and d input; bn1's mask / reduction rides on the d input ---------------
         dw2 = None
+        dz1 = torch.empty((Rin, p), **f32)         # first d a1 (masked), then (in place) dz1
         if CONV3 == "hip":
             if need[5]:
                 dw2 = _grad_out(w2)
                 sw, wsw = (side.fork(main, dz2, a1, dw2), side.ws) if side else (st, ws)
                 _chk(h.scnattn_conv3x3_wgrad(sw, N, Hi, Wi, p, p, s, dz2.data_ptr(), a1.data_ptr(), dw2.data_ptr(),
                                              wsw.data_ptr(), wsw.numel(), W3_SLICES), "scnattn_conv3x3_wgrad")
-            da1 = torch.empty((Rin, p), **f32)
-            if s == 1:
-                _chk(h.scnattn_conv3x3_dgrad(st, N, Hi, Wi, p, p, dz2.data_ptr(), w2.data_ptr(), da1.data_ptr(), None,
+            if s == 1:      # mask = [fma((z1-mean)*invstd, gamma, beta) > 0]: the expression bn1's apply evaluated
+                ex = ConvExtra(epi=2, stat_partial=part.data_ptr(), ez=z1.data_ptr(), emean=st1[0].data_ptr(),
+                               einvstd=st1[1].data_ptr(), egamma=g1.data_ptr(), ebeta=b1.data_ptr(), ldz=p)
+                _chk(h.scnattn_conv3x3_dgrad(st, N, Hi, Wi, p, p, dz2.data_ptr(), w2.data_ptr(), dz1.data_ptr(), C.byref(ex),
                                              ws.data_ptr(), ws.numel()), "scnattn_conv3x3_dgrad")
+                dgb1 = _bwd_dx_fin(h, st, Rin, p, dz1, z1, st1, g1, part, ld_in, nc_in, dz1)
             else:
+                da1 = torch.empty((Rin, p), **f32)
                 _chk(h.scnattn_conv3x3_dgrad_strided(st, N, Hi, Wi, p, p, s, dz2.data_ptr(), w2.data_ptr(), da1.data_ptr(),
                                                      ws.data_ptr(), ws.numel()), "scnattn_conv3x3_dgrad_strided")
         else:       # A/B only: MIOpen
@@ -417,13 +462,11 @@ class _BottleneckFn(torch.autograd.Function):
             if not da1_4.is_contiguous(memory_format=torch.channels_last):
                 da1_4 = da1_4.contiguous(memory_format=torch.channels_last)
             da1 = _as2d(da1_4)
-        # ---- bn1 (+ relu, mask recomputed from z1) ----------------------------------------------------------------
+        if not (CONV3 == "hip" and s == 1):     # the mask comes from a1 itself: a1 = relu(bn1(z1)) > 0
+            g1m, nch = _bwd_reduce(h, st, Rin, p, da1, a1, z1, st1, True, bnpart, True)
+            dgb1 = _bwd_dx_fin(h, st, Rin, p, g1m, z1, st1, g1, bnpart, (nch + 3) & ~3, nch, dz1)
+            del g1m, da1
         need_dx = need[1]
-        dz1 = torch.empty((Rin, p), **f32)
-        dgb1 = torch.empty((2, p), **f32)
-        _chk(h.scnattn_bn_bwd(st, Rin, p, da1.data_ptr(), None, z1.data_ptr(), 0, st1[0].data_ptr(), st1[1].data_ptr(),
-                              g1.data_ptr(), b1.data_ptr(), 1, 1, bnpart.data_ptr(), dgb1[0].data_ptr(), dgb1[1].data_ptr(),
-                              dz1.data_ptr(), None), "scnattn_bn_bwd")
         dw1 = None
         if need[2]:
             dw1 = _grad_out(w1)
@@ -432,14 +475,18 @@ class _BottleneckFn(torch.autograd.Function):
             _chk(h.scnattn_conv1x1_wgrad(sw, Rin, Cin, p, dz1.data_ptr(), x2.data_ptr(), dw1.data_ptr(), C.byref(ex1),
                                          wsw.data_ptr(), wsw.numel()), "scnattn_conv1x1_wgrad")
         # ---- identity branch and d x --------------------------------------------------------------------------------
+        wt = ctx.wt
+        if need_dx:
+            if wt is None:
+                wt = _wt(h, st, w1, p, Cin)
+            else:
+                main.wait_event(ctx.wt_ev)
         dwd = dgbd = None
         dx = None
         if ctx.has_down:
+            _, nch = _bwd_reduce(h, st, Rout, C4, dres, None, zd, std, False, bnpart, False)
             dzd = torch.empty((Rout, C4), **f32)
-            dgbd = torch.empty((2, C4), **f32)
-            _chk(h.scnattn_bn_bwd(st, Rout, C4, dres.data_ptr(), None, zd.data_ptr(), 0, std[0].data_ptr(),
-                                  std[1].data_ptr(), gd.data_ptr(), None, 0, 1, bnpart.data_ptr(), dgbd[0].data_ptr(),
-                                  dgbd[1].data_ptr(), dzd.data_ptr(), None), "scnattn_bn_bwd")
+            dgbd = _bwd_dx_fin(h, st, Rout, C4, dres, zd, std, gd, bnpart, (nch + 3) & ~3, nch, dzd)
             if need[11]:
                 dwd = _grad_out(wd)
                 ex = ConvExtra(stride=s, Hi=Hi, Wi=Wi, Ho=Ho, Wo=Wo)
@@ -448,7 +495,7 @@ class _BottleneckFn(torch.autograd.Function):
                                              C.byref(ex), wsw.data_ptr(), wsw.numel()), "scnattn_conv1x1_wgrad")
             if need_dx:
                 dx = torch.empty((Rin, Cin), **f32)
-                _chk(h.scnattn_conv1x1_dgrad(st, Rin, Cin, p, dz1.data_ptr(), _wt(h, st, w1, p, Cin).data_ptr(), 1, 0.0,
+                _chk(h.scnattn_conv1x1_dgrad(st, Rin, Cin, p, dz1.data_ptr(), wt.data_ptr(), 1, 0.0,
                                              dx.data_ptr(), None, ws.data_ptr(), ws.numel()), "scnattn_conv1x1_dgrad")
                 dxd = torch.empty((Rout, Cin), **f32)
                 _chk(h.scnattn_conv1x1_dgrad(st, Rout, Cin, C4, dzd.data_ptr(), wd.data_ptr(), 0, 0.0, dxd.data_ptr(), None,
@@ -458,7 +505,7 @@ class _BottleneckFn(torch.autograd.Function):
         elif need_dx:
             # d x = d identity + dz1 . W1, accumulated in place (beta = 1): no residual-gradient add kernel
             dx = dres
-            _chk(h.scnattn_conv1x1_dgrad(st, Rin, Cin, p, dz1.data_ptr(), _wt(h, st, w1, p, Cin).data_ptr(), 1, 1.0,
+            _chk(h.scnattn_conv1x1_dgrad(st, Rin, Cin, p, dz1.data_ptr(), wt.data_ptr(), 1, 1.0,
                                          dx.data_ptr(), None, ws.data_ptr(), ws.numel()), "scnattn_conv1x1_dgrad")
         if side:
             side.mark()      # joined by the first reader of the weight gradients (FlatBuffer.gather)

@@ -53,14 +53,17 @@ def stem(trunk, x):
         if not getattr(bn, "counter_managed", False) and bn.num_batches_tracked is not None:
             bn.num_batches_tracked.add_(1)
         nt = h.scnattn_stem_tiles(N, H, W)
-        part = torch.empty((nt, 2, 64), device=dev, dtype=torch.float32)
+        ldp = (nt + 3) & ~3
+        part = torch.empty((2, 64, ldp), device=dev, dtype=torch.float32)     # channel-major partials, one entry per workgroup
         stats = torch.empty((2, 64), device=dev, dtype=torch.float32)
+        shift = _conv._shift(bn)
         _conv._chk(h.scnattn_stem_conv7(st, N, H, W, x.data_ptr(), *x.stride(), w.data_ptr(), *w.stride(), z.data_ptr(),
-                                        part.data_ptr(), bn.running_mean.data_ptr()), "scnattn_stem_conv7")
-        _conv._chk(h.scnattn_bn_finalize(st, N * Hz * Wz, 64, nt, part.data_ptr(), bn.running_mean.data_ptr(), bn.eps,
+                                        part.data_ptr(), shift.data_ptr()), "scnattn_stem_conv7")
+        _conv._chk(h.scnattn_bn_finalize(st, N * Hz * Wz, 64, part.data_ptr(), ldp, nt, shift.data_ptr(), bn.eps,
                                          bn.momentum, stats[0].data_ptr(), stats[1].data_ptr(),
                                          bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.weight.data_ptr(),
                                          bn.bias.data_ptr(), ss.data_ptr()), "scnattn_bn_finalize")
+        bn._scn_shift = stats[0]
     else:
         _conv._chk(h.scnattn_stem_conv7(st, N, H, W, x.data_ptr(), *x.stride(), w.data_ptr(), *w.stride(), z.data_ptr(),
                                         None, None), "scnattn_stem_conv7")

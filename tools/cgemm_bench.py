@@ -61,7 +61,7 @@ def check():
             e = rel(y, xd @ wd.t()); worst = max(worst, e); assert e < 3e-6, ("fwd", R, Cin, Cout, split, e)
             # fwd prologue + stats epilogue
             mt = lib().scnattn_cgemm_row_tiles(R)
-            part = torch.full((mt, 2, Cout), float("nan"), device=dev)
+            part = torch.full((2, Cout, lib().scnattn_cgemm_stat_ld(R)), float("nan"), device=dev)
             sft = (0.1 * torch.randn(Cout, generator=g)).to(dev)
             ex = ConvExtra(pro=1, epi=1, pro_ss=ss.data_ptr(), stat_partial=part.data_ptr(),
                            stat_shift=sft.data_ptr(), force_split=split)
@@ -70,7 +70,7 @@ def check():
             y_ref = a_ref @ wd.t()
             e = rel(y, y_ref); worst = max(worst, e); assert e < 3e-6, ("fwd pro", R, Cin, Cout, split, e)
             d = y_ref - sft.double()
-            e1 = rel(part[:, 0].double().sum(0), d.sum(0)); e2 = rel(part[:, 1].double().sum(0), (d * d).sum(0))
+            e1 = rel(part[0, :, :mt].double().sum(1), d.sum(0)); e2 = rel(part[1, :, :mt].double().sum(1), (d * d).sum(0))
             assert e1 < 2e-5 and e2 < 2e-5, ("stats", R, Cin, Cout, split, e1, e2)
             # dgrad plain + beta
             dx0 = torch.randn(R, Cin, generator=g).to(dev)
@@ -81,7 +81,7 @@ def check():
                 z = torch.randn(R, Cin, generator=g).to(dev)
                 mu = (0.1 * torch.randn(Cin, generator=g)).to(dev); isd = (1 + 0.2 * torch.rand(Cin, generator=g)).to(dev)
                 ga = (1 + 0.3 * torch.randn(Cin, generator=g)).to(dev); be = (0.2 * torch.randn(Cin, generator=g)).to(dev)
-                part = torch.full((mt, 2, Cin), float("nan"), device=dev)
+                part = torch.full((2, Cin, lib().scnattn_cgemm_stat_ld(R)), float("nan"), device=dev)
                 ex = ConvExtra(epi=2, stat_partial=part.data_ptr(), ez=z.data_ptr(), emean=mu.data_ptr(), einvstd=isd.data_ptr(),
                                egamma=ga.data_ptr(), ebeta=be.data_ptr(), ldz=Cin, force_split=split)
                 gk = cgemm(dy, w, False, False, torch.empty(R, Cin, device=dev), R, Cin, Cout, ex)
@@ -89,7 +89,7 @@ def check():
                 mask = (torch.addcmul(be, xh, ga) > 0)
                 g_ref = (dyd @ wd) * mask.double()
                 e = rel(gk, g_ref); assert e < 3e-6, ("dgrad mask", R, Cin, Cout, split, e)
-                e1 = rel(part[:, 0].double().sum(0), g_ref.sum(0)); e2 = rel(part[:, 1].double().sum(0), (g_ref * xh.double()).sum(0))
+                e1 = rel(part[0, :, :mt].double().sum(1), g_ref.sum(0)); e2 = rel(part[1, :, :mt].double().sum(1), (g_ref * xh.double()).sum(0))
                 assert e1 < 2e-5 and e2 < 2e-5, ("mask stats", R, Cin, Cout, split, e1, e2)
             # wgrad plain and with the B prologue
             if Cout % 4 == 0 and Cin % 4 == 0 and (split <= 1 or R // split >= 16):
@@ -117,12 +117,12 @@ def check():
         sc = (1 + 0.5 * torch.randn(Cin, generator=g)).to(dev); sh = (0.2 * torch.randn(Cin, generator=g)).to(dev)
         ss = torch.stack([sc, sh], dim=1).contiguous()
         for split in (0, 2):
-            part = torch.full((lib().scnattn_cgemm_row_tiles(R), 2, Cout), float("nan"), device=dev)
+            part = torch.full((2, Cout, lib().scnattn_cgemm_stat_ld(R)), float("nan"), device=dev); mt = lib().scnattn_cgemm_row_tiles(R)
             ex = ConvExtra(pro=1, epi=1, pro_ss=ss.data_ptr(), stat_partial=part.data_ptr(), force_mi=4, force_split=split)
             y = cgemm(x, w, False, True, torch.empty(R, Cout, device=dev), R, Cout, Cin, ex)
             y_ref = torch.relu(x.double() * sc.double() + sh.double()) @ w.double().t()
             e = rel(y, y_ref); assert e < 3e-6, ("w41 fwd", R, Cin, Cout, split, e)
-            e1 = rel(part[:, 0].double().sum(0), y_ref.sum(0)); e2 = rel(part[:, 1].double().sum(0), (y_ref * y_ref).sum(0))
+            e1 = rel(part[0, :, :mt].double().sum(1), y_ref.sum(0)); e2 = rel(part[1, :, :mt].double().sum(1), (y_ref * y_ref).sum(0))
             assert e1 < 2e-5 and e2 < 2e-5, ("w41 stats", R, Cin, Cout, split, e1, e2)
             dx = cgemm(dy, w, False, False, torch.empty(R, Cin, device=dev), R, Cin, Cout, ConvExtra(force_mi=4, force_split=split))
             e = rel(dx, dy.double() @ w.double()); assert e < 3e-6, ("w41 dgrad", R, Cin, Cout, split, e)
@@ -150,7 +150,7 @@ def timeit():
         sc = torch.rand(Cin, device=dev) + 0.5; sh = torch.randn(Cin, device=dev) * 0.1
         ss = torch.stack([sc, sh], dim=1).contiguous()
         mt = lib().scnattn_cgemm_row_tiles(R)
-        part = torch.empty(mt, 2, max(Cin, Cout), device=dev)
+        part = torch.empty(2, max(Cin, Cout), lib().scnattn_cgemm_stat_ld(R), device=dev)
         z = torch.randn(R, Cin, device=dev); v = torch.rand(Cin, device=dev) + 0.5
         exf = ConvExtra(pro=1, epi=1, pro_ss=ss.data_ptr(), stat_partial=part.data_ptr())
         exd = ConvExtra(epi=2, stat_partial=part.data_ptr(), ez=z.data_ptr(), emean=sh.data_ptr(), einvstd=v.data_ptr(),
@@ -250,6 +250,65 @@ def check3():
     print("check3 ok", flush=True)
 
 
+def checkbn():
+    """Finalize-on-load BatchNorm kernels (csrc/batchnorm.hip) against fp64: apply (+res, +relu) with statistics from
+    channel-major partials, backward reduce (mask from y) + dx with d beta / d gamma summed inside."""
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for (R, Cn) in [(2048, 512), (8192, 256), (300, 48), (131072, 64), (70, 2048), (32768, 128)]:
+        z = (torch.randn(R, Cn, generator=g) * (0.5 + torch.rand(Cn, generator=g)) + torch.randn(Cn, generator=g)).to(dev)
+        res = torch.randn(R, Cn, generator=g).to(dev)
+        ga = (1 + 0.3 * torch.randn(Cn, generator=g)).to(dev); be = (0.2 * torch.randn(Cn, generator=g)).to(dev)
+        shift = (z.mean(0) + 0.1 * torch.randn(Cn, device=dev)).contiguous()
+        mt = lib().scnattn_cgemm_row_tiles(R); ld = lib().scnattn_cgemm_stat_ld(R)
+        part = torch.full((2, Cn, ld), float("nan"), device=dev)
+        d = (z - shift).double()
+        nfull = (R // 64) * 64
+        p1 = d[:nfull].view(-1, 64, Cn).sum(1); p2 = (d[:nfull] ** 2).view(-1, 64, Cn).sum(1)
+        if nfull < R:
+            p1 = torch.cat([p1, d[nfull:].sum(0, keepdim=True)]); p2 = torch.cat([p2, (d[nfull:] ** 2).sum(0, keepdim=True)])
+        part[0, :, :mt] = p1.t().float(); part[1, :, :mt] = p2.t().float()
+        zd = z.double(); mu = zd.mean(0); var = zd.var(0, unbiased=False); eps, mom = 1e-5, 0.1
+        for relu in (0, 1):
+            for use_res in (False, True):
+                y = torch.full((R, Cn), float("nan"), device=dev); st = torch.empty(2, Cn, device=dev)
+                rm = torch.zeros(Cn, device=dev); rv = torch.ones(Cn, device=dev); ss = torch.empty(Cn, 2, device=dev)
+                call("scnattn_bn_apply_fin", stream_of(z), R, Cn, ptr(z), ptr(res) if use_res else None, ptr(part), ld, mt, ptr(shift),
+                     eps, mom, ptr(ga), ptr(be), relu, ptr(y), ptr(st[0]), ptr(st[1]), ptr(rm), ptr(rv), ptr(ss))
+                ref = (zd - mu) / torch.sqrt(var + eps) * ga.double() + be.double()
+                if use_res: ref = ref + res.double()
+                if relu: ref = torch.relu(ref)
+                e = rel(y, ref); assert e < 1e-5, ("bn_apply_fin", R, Cn, relu, use_res, e)
+                assert rel(st[0], mu) < 1e-5 and rel(st[1], 1 / torch.sqrt(var + eps)) < 1e-5
+                assert rel(rm, mom * mu) < 1e-5 and rel(rv, 0.9 + mom * zd.var(0, unbiased=True)) < 1e-5
+                sc = ga.double() / torch.sqrt(var + eps)
+                assert rel(ss[:, 0], sc) < 1e-5 and (ss[:, 1].double() - (be.double() - mu * sc)).abs().max() < 1e-4
+        st2 = torch.empty(2, Cn, device=dev)
+        call("scnattn_bn_finalize", stream_of(z), R, Cn, ptr(part), ld, mt, ptr(shift), eps, mom, ptr(st2[0]), ptr(st2[1]), None, None, None, None, None)
+        assert torch.equal(st2, st), "finalize and finalize-on-load must give the same bits"
+        # backward
+        dy = torch.randn(R, Cn, generator=g).to(dev)
+        yv = torch.relu(torch.randn(R, Cn, generator=g)).to(dev)
+        cap = 260
+        bpart = torch.full((2, Cn, cap), float("nan"), device=dev)
+        gout = torch.full((R, Cn), float("nan"), device=dev)
+        nch = C.c_int(0)
+        call("scnattn_bn_bwd_reduce", stream_of(z), R, Cn, ptr(dy), ptr(yv), ptr(z), ptr(st[0]), ptr(st[1]), 1, ptr(bpart), cap, ptr(gout), C.byref(nch))
+        gref = dy.double() * (yv > 0).double()
+        assert torch.equal(gout.double(), gref)
+        xh = (zd - st[0].double()) * st[1].double()
+        ldb = (nch.value + 3) & ~3          # the kernel packs the partial with this leading dimension
+        bp = bpart.view(-1)[:2 * Cn * ldb].view(2, Cn, ldb)
+        e1 = rel(bp[0, :, :nch.value].double().sum(1), gref.sum(0)); e2 = rel(bp[1, :, :nch.value].double().sum(1), (gref * xh).sum(0))
+        assert e1 < 2e-5 and e2 < 2e-5, ("bn_bwd_reduce", R, Cn, e1, e2)
+        dz = torch.full((R, Cn), float("nan"), device=dev); dgb = torch.empty(2, Cn, device=dev)
+        call("scnattn_bn_bwd_dx_fin", stream_of(z), R, Cn, ptr(gout), ptr(z), ptr(st[0]), ptr(st[1]), ptr(ga), ptr(bp), ldb, nch.value, ptr(dgb[0]), ptr(dgb[1]), ptr(dz))
+        db, dg = gref.sum(0), (gref * xh).sum(0)
+        dzr = ga.double() * st[1].double() * (gref - db / R - xh * dg / R)
+        assert rel(dgb[0], db) < 2e-5 and rel(dgb[1], dg) < 2e-5
+        e = rel(dz, dzr); assert e < 2e-5, ("bn_bwd_dx_fin", R, Cn, e)
+    print("checkbn ok", flush=True)
+
+
 def checkstem():
     g = torch.Generator(device="cpu").manual_seed(2)
     for (N, H, W, cl_x, cl_w) in [(2, 64, 64, False, True), (3, 50, 70, True, True), (1, 33, 17, False, False), (32, 256, 256, True, True)]:
@@ -260,13 +319,13 @@ def checkstem():
         Hz, Wz = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         nt = lib().scnattn_stem_tiles(N, H, W)
         z = torch.full((N * Hz * Wz, 64), float("nan"), device=dev)
-        part = torch.full((nt, 2, 64), float("nan"), device=dev)
+        mt = nt; part = torch.full((2, 64, (nt + 3) & ~3), float("nan"), device=dev)
         sft = (0.1 * torch.randn(64, generator=g)).to(dev)
         call("scnattn_stem_conv7", stream_of(x), N, H, W, ptr(x), *x.stride(), ptr(w), *w.stride(), ptr(z), ptr(part), ptr(sft))
         ref = F.conv2d(x.double(), w.double(), stride=2, padding=3).permute(0, 2, 3, 1).reshape(-1, 64)
         e = rel(z, ref); assert e < 3e-6, ("stem conv7", N, H, W, e)
         d = ref - sft.double()
-        e1 = rel(part[:, 0].double().sum(0), d.sum(0)); e2 = rel(part[:, 1].double().sum(0), (d * d).sum(0))
+        e1 = rel(part[0, :, :mt].double().sum(1), d.sum(0)); e2 = rel(part[1, :, :mt].double().sum(1), (d * d).sum(0))
         assert e1 < 2e-5 and e2 < 2e-5, ("stem stats", N, H, W, e1, e2)
         ss = torch.stack([1 + 0.5 * torch.randn(64, generator=g), 0.3 * torch.randn(64, generator=g)], dim=1).to(dev).contiguous()
         Hp, Wp = (Hz - 1) // 2 + 1, (Wz - 1) // 2 + 1
@@ -313,7 +372,7 @@ def time3():
     w = (0.1 * torch.randn(64, 3, 7, 7, device=dev)).contiguous(memory_format=torch.channels_last)
     z = torch.empty(N * 128 * 128, 64, device=dev); out = torch.empty(N * 64 * 64, 64, device=dev)
     nt = lib().scnattn_stem_tiles(N, H, H)
-    part = torch.empty(nt, 2, 64, device=dev); ss = torch.rand(64, 2, device=dev)
+    part = torch.empty(2, 64, (nt + 3) & ~3, device=dev); ss = torch.rand(64, 2, device=dev)
     c0 = t_us(lambda: call("scnattn_stem_conv7", stream_of(x), N, H, H, ptr(x), *x.stride(), ptr(w), *w.stride(), ptr(z), ptr(part), None))
     c1 = t_us(lambda: F.conv2d(x, w, stride=2, padding=3))
     p0 = t_us(lambda: call("scnattn_stem_bn_relu_maxpool", stream_of(x), N, 128, 128, 64, ptr(z), ptr(ss), ptr(out)))
@@ -334,7 +393,7 @@ def ab():
         x = torch.randn(R, Cin, device=dev); w = torch.randn(Cout, Cin, device=dev) * 0.1; y = torch.empty(R, Cout, device=dev)
         dy = torch.randn(R, Cout, device=dev); dx = torch.empty(R, Cin, device=dev); dw = torch.empty(Cout, Cin, device=dev)
         ss = torch.rand(Cin, 2, device=dev); z = torch.randn(R, Cin, device=dev); v = torch.rand(Cin, device=dev) + 0.5
-        part = torch.empty(lib().scnattn_cgemm_row_tiles(R), 2, max(Cin, Cout), device=dev)
+        part = torch.empty(2, max(Cin, Cout), lib().scnattn_cgemm_stat_ld(R), device=dev)
         ex_p = ConvExtra(pro=1, pro_ss=ss.data_ptr())
         ex_e = ConvExtra(epi=1, stat_partial=part.data_ptr())
         ex_b = ConvExtra(pro=1, epi=1, pro_ss=ss.data_ptr(), stat_partial=part.data_ptr())
@@ -367,7 +426,7 @@ def stagger():
         x = torch.randn(R, Cin, device=dev); w = torch.randn(Cout, Cin, device=dev) * 0.1; y = torch.empty(R, Cout, device=dev)
         dy = torch.randn(R, Cout, device=dev); dx = torch.empty(R, Cin, device=dev)
         ss = torch.rand(Cin, 2, device=dev)
-        part = torch.empty(lib().scnattn_cgemm_row_tiles(R), 2, max(Cin, Cout), device=dev)
+        part = torch.empty(2, max(Cin, Cout), lib().scnattn_cgemm_stat_ld(R), device=dev)
         ex_b = ConvExtra(pro=1, epi=1, pro_ss=ss.data_ptr(), stat_partial=part.data_ptr())
         f, d = [], []
         for v in vals:
@@ -389,7 +448,7 @@ def sweep3():
         w = (0.1 * torch.randn(Cout, Cin, 3, 3, device=dev)).contiguous(memory_format=torch.channels_last)
         dy = torch.randn(N, Cout, H, H, device=dev).contiguous(memory_format=torch.channels_last)
         y = torch.empty(N * H * H, Cout, device=dev); dx = torch.empty_like(x)
-        part = torch.empty(lib().scnattn_cgemm_row_tiles(N * H * H), 2, Cout, device=dev)
+        part = torch.empty(2, Cout, lib().scnattn_cgemm_stat_ld(N * H * H), device=dev)
         for kind in ("fwd+stats", "dgrad"):
             ts = []
             for mi, S in combos + [(0, 0)]:
@@ -486,5 +545,7 @@ if __name__ == "__main__":
         check3()
     if what in ("checkstem", "all3"):
         checkstem()
+    if what in ("checkbn", "all3"):
+        checkbn()
     if what in ("time3", "all3"):
         time3()
