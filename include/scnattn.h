@@ -23,26 +23,24 @@
 extern "C" {
 #endif
 
-#define SCNATTN_VERSION 107 /* 0.1.7: + halo-staged 3x3 weight gradient, strided 3x3 d input, the stem (scnattn_stem_*) */
+#define SCNATTN_VERSION 107 /* 0.1.7: + halo-staged 3x3 weight gradient, strided 3x3 d input, the stem (scnattn_stem_*), BatchNorm
+                               finalize on load; - whole-block drivers, scnattn_stream_*, the experiment options of rounds 1-2 */
 
 int scnattn_version(void);
 const char* scnattn_last_error(void);
-/* Options: "ksplit" (force the split-K factor of the skinny GEMMs; 0 = auto), "profile" (1: bracket
- * the recurrence loops with HIP events on the caller's stream; 2: also every attn_context launch),
- * "chains" (1, default; 2: the recurrence is enqueued as two independent half-batch dependency chains,
- * chain 0 on the caller's stream and chain 1 on a library-owned side stream by a helper thread,
- * forked and joined with events so the call stays ordered on the caller's stream; bit-identical, slower),
- * "fuse_attn" (1: scores+softmax+context in one launch; slower, default 0),
- * "attn_handoff" (1: on the pooled path the attention scores and the context run as ONE launch whose E-chunk
- * workgroups share the scores of a batch row through an in-launch hand-off; default 0 = two launches: measured equal),
- * "handoff_check" (1: scnattn_seq_fwd synchronises at its end and returns an error if a hand-off wait timed out),
- * "decoder_bf16" (1; 2 = the same plus the bf16 matrix instruction in the per-step products: the sequence drivers stream bf16 copies of the recurrent weights, att1 and the encoder map --
- * see scnattn_skinny_gemm_bf16w; needs D, F, E, A multiples of 4, otherwise the fp32 path runs),
- * tuning of the dense / convolution GEMM (csrc/cgemm.hip): "use_cgemm" (0: every product on the round-1 sgemm kernel),
- * "cgemm_mi" (0 auto; 1 / 2 force the 64- / 128-row tile), "cgemm_target" (workgroups a split-K product aims for, 512),
- * "cgemm_kmin" (smallest K per slab, 128), "cgemm_vec" (0: scalar epilogue), "cgemm_w41" (0: never the 128 x 64 tile
- * with the 4 x 1 wave layout), "cgemm_stagger" (start delay per residency round in units of 64 cycles; experiment).
- * Returns -1 for an unknown name or value. */
+/* Process-wide options.  Every entry point is re-entrant and takes its stream explicitly; what is left here is
+ *   - what a caller chooses once per process: "decoder_bf16" (0 fp32; 1: the sequence drivers stream bf16 copies of the
+ *     recurrent weights, att1 and the encoder map, fp32 accumulate / state / gradients; 2: also the bf16 matrix
+ *     instruction in the per-step products -- BASELINE configs[4]; needs D, F, E, A multiples of 4) and "profile" (1: bracket
+ *     the recurrence loops with HIP events on the caller's stream; 2: also every attn_context launch; see
+ *     scnattn_profile_collect);
+ *   - policy overrides used by tools/ sweeps and the tests that cover both sides of a policy: "ksplit" (split-K factor of the
+ *     skinny GEMMs; 0 = auto), "attn_depth", "use_cgemm" (0: every dense product on the round-1 sgemm kernel), "cgemm_mi"
+ *     (0 auto; 1 / 2 force the 64- / 128-row tile), "cgemm_target" (workgroups a split-K product aims for, 512),
+ *     "cgemm_kmin" (smallest K per slab, 128), "gemm_target" / "gemm_gate" / "gemm_kmin" / "gemm_kmin_small" (the same for
+ *     sgemm).  The experiment switches of rounds 1-2 (fuse_attn, chains, attn_handoff, cgemm_stagger, cgemm_w41, cgemm_vec,
+ *     bn_gfirst, skinny_tail) were removed together with the code paths they selected; DESIGN.md keeps their numbers.
+ * Returns -1 for an unknown name or an out-of-range value. */
 int scnattn_set_option(const char* name, int value);
 /* Sums since the last call: out6 = {forward loop ms, forward steps, backward loop ms, backward steps,
  * attn_context ms, attn_context launches}.  Synchronises on the recorded events. */
@@ -188,12 +186,6 @@ int scnattn_skinny_gemm_bf16(void* stream, int rows, int N, int K, int groups, c
                              int ksplit, int* ksplit_out);
 int scnattn_f32_to_bf16(void* stream, long n, const float* in, void* out);
 
-/* HIP streams with an explicit priority for hosts whose framework cannot create them (PyTorch exposes only "normal" and
- * "high"): the weight-gradient / communication side streams of a train step are created at the LOWEST priority the
- * device offers, so that the kernels of the critical path are dispatched first wherever both streams have work. */
-int scnattn_stream_priority_range(int* least, int* greatest);
-int scnattn_stream_create(int priority, void** out);
-int scnattn_stream_destroy(void* stream);
 /* models/attention.py:37-39 */
 int scnattn_attn_scores(void* stream, int rows, int P, int A, const float* att1, const float* att2, int nslab,
                         long slab_stride, long att2_ld, const float* dec_bias, const float* w, const float* b0,

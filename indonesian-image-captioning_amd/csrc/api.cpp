@@ -21,11 +21,9 @@ const char* last_error() { return g_err; }
 
 extern int g_ksplit_scale;
 extern int g_profile;
-extern int g_fuse_attn;
-extern int g_chains;
 extern int g_attn_depth;
-extern int g_attn_handoff, g_handoff_check, g_dec_bf16;
-extern int g_gemm_target, g_gemm_kmin, g_gemm_kmin_small, g_gemm_gate, g_use_cgemm, g_cgemm_target, g_cgemm_kmin, g_cgemm_vec, g_cgemm_mi, g_cgemm_stagger, g_cgemm_w41, g_bn_gfirst, g_skinny_tail;
+extern int g_dec_bf16;
+extern int g_gemm_target, g_gemm_kmin, g_gemm_kmin_small, g_gemm_gate, g_use_cgemm, g_cgemm_target, g_cgemm_kmin, g_cgemm_mi;
 int profile_collect(double* out);
 int seq_workspace(const scnattn_dims* d, const scnattn_pool* pool, size_t* saved_bytes, size_t* scratch_bytes);
 int seq_fwd(hipStream_t st, const scnattn_dims* d, const scnattn_params* w, const float* enc, const float* tags,
@@ -46,41 +44,27 @@ extern "C" {
 int scnattn_version(void) { return SCNATTN_VERSION; }
 const char* scnattn_last_error(void) { return last_error(); }
 
+// Process-wide knobs.  Two kinds only (the experiment switches of rounds 1-2 -- fuse_attn, chains,
+// attn_handoff, cgemm_stagger, cgemm_w41, cgemm_vec, bn_gfirst, skinny_tail -- are gone with the code paths they selected):
+//   * what a CALLER chooses per process: "decoder_bf16" (storage mode of the decode step, BASELINE configs[4]), "profile"
+//     (HIP-event timing of the recurrence loops for bench.py);
+//   * split-K / tile policy overrides that only tools/ (sweeps) and the tests of both policies set.
 int scnattn_set_option(const char* name, int value) {
-    if (name && std::strcmp(name, "ksplit") == 0) {
-        g_ksplit_scale = value;
-        return 0;
-    }
-    if (name && std::strcmp(name, "fuse_attn") == 0) {
-        g_fuse_attn = value;
-        return 0;
-    }
-    if (name && std::strcmp(name, "chains") == 0) {
-        if (value != 1 && value != 2) { set_error("scnattn_set_option: chains must be 1 or 2"); return -1; }
-        g_chains = value;
-        return 0;
-    }
-    if (name && std::strcmp(name, "attn_depth") == 0) { g_attn_depth = value != 0; return 0; }
-    if (name && std::strcmp(name, "attn_handoff") == 0) { g_attn_handoff = value != 0; return 0; }
-    if (name && std::strcmp(name, "decoder_bf16") == 0 && value >= 0 && value <= 2) { g_dec_bf16 = value; return 0; }
-    if (name && std::strcmp(name, "handoff_check") == 0) { g_handoff_check = value != 0; return 0; }
-    if (name && std::strcmp(name, "gemm_target") == 0 && value >= 1) { g_gemm_target = value; return 0; }
-    if (name && std::strcmp(name, "gemm_gate") == 0 && value >= 1) { g_gemm_gate = value; return 0; }
-    if (name && std::strcmp(name, "gemm_kmin") == 0 && value >= 16) { g_gemm_kmin = value; return 0; }
-    if (name && std::strcmp(name, "gemm_kmin_small") == 0 && value >= 16) { g_gemm_kmin_small = value; return 0; }
-    if (name && std::strcmp(name, "use_cgemm") == 0) { g_use_cgemm = value != 0; return 0; }
-    if (name && std::strcmp(name, "cgemm_vec") == 0) { g_cgemm_vec = value != 0; return 0; }
-    if (name && std::strcmp(name, "cgemm_mi") == 0 && value >= 0 && value <= 2) { g_cgemm_mi = value; return 0; }
-    if (name && std::strcmp(name, "skinny_tail") == 0) { g_skinny_tail = value != 0; return 0; }
-    if (name && std::strcmp(name, "bn_gfirst") == 0) { g_bn_gfirst = value != 0; return 0; }
-    if (name && std::strcmp(name, "cgemm_w41") == 0) { g_cgemm_w41 = value != 0; return 0; }
-    if (name && std::strcmp(name, "cgemm_stagger") == 0 && value >= 0 && value <= 4096) { g_cgemm_stagger = value; return 0; }
-    if (name && std::strcmp(name, "cgemm_target") == 0 && value >= 1) { g_cgemm_target = value; return 0; }
-    if (name && std::strcmp(name, "cgemm_kmin") == 0 && value >= 16) { g_cgemm_kmin = value; return 0; }
-    if (name && std::strcmp(name, "profile") == 0) {
-        g_profile = value;
-        return 0;
-    }
+    struct Opt { const char* name; int* var; int lo, hi; };
+    static const Opt opts[] = {
+        {"decoder_bf16", &g_dec_bf16, 0, 2},   {"profile", &g_profile, 0, 2},
+        {"ksplit", &g_ksplit_scale, 0, SCN_MAX_KSPLIT}, {"attn_depth", &g_attn_depth, 0, 1},
+        {"use_cgemm", &g_use_cgemm, 0, 1},     {"cgemm_mi", &g_cgemm_mi, 0, 2},
+        {"cgemm_target", &g_cgemm_target, 1, 1 << 20}, {"cgemm_kmin", &g_cgemm_kmin, 16, 1 << 20},
+        {"gemm_target", &g_gemm_target, 1, 1 << 20},   {"gemm_gate", &g_gemm_gate, 1, 1 << 20},
+        {"gemm_kmin", &g_gemm_kmin, 16, 1 << 20},      {"gemm_kmin_small", &g_gemm_kmin_small, 16, 1 << 20},
+    };
+    for (const Opt& o : opts)
+        if (name && std::strcmp(name, o.name) == 0) {
+            if (value < o.lo || value > o.hi) { set_error("scnattn_set_option: %s out of range [%d, %d]", o.name, o.lo, o.hi); return -1; }
+            *o.var = value;
+            return 0;
+        }
     set_error("scnattn_set_option: unknown option '%s'", name ? name : "(null)");
     return -1;
 }
@@ -286,27 +270,6 @@ int scnattn_skinny_gemm_bf16w(void* stream, int rows, int N, int K, int groups, 
     if (ksplit <= 0) ksplit = skinny_pick_ksplit(rows, N, K, groups);
     if (ksplit_out) *ksplit_out = ksplit;
     return skinny_gemm(ST(stream), rows, N, K, groups, X, ldx, xg, W_bf16, ldw, wg, Y, ldy, yg, yslab, ksplit, 1);
-}
-
-int scnattn_stream_priority_range(int* least, int* greatest) {
-    int lo = 0, hi = 0;
-    SCN_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    if (least) *least = lo;
-    if (greatest) *greatest = hi;
-    return 0;
-}
-
-int scnattn_stream_create(int priority, void** out) {
-    SCN_ARG(out, "stream_create: NULL");
-    hipStream_t s = nullptr;
-    SCN_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority));
-    *out = s;
-    return 0;
-}
-
-int scnattn_stream_destroy(void* stream) {
-    if (stream) SCN_HIP(hipStreamDestroy(ST(stream)));
-    return 0;
 }
 
 int scnattn_skinny_gemm_bf16(void* stream, int rows, int N, int K, int groups, const float* X, long ldx, long xg,

@@ -520,7 +520,6 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(long n4, int R, int C, c
 }
 
 }  // namespace
-int g_bn_gfirst = 1;      // 1: see bn_bwd_t (option "bn_gfirst", A/B)
 namespace {
 
 inline int pick_chunks(int R, int C, int* rows_per_chunk) {
@@ -602,7 +601,7 @@ static int bn_bwd_t(hipStream_t st, int R, int C, const T* dy, const T* y, const
     const bool maskz = relu && !y;       // ReLU mask recomputed from z (no residual in front of the ReLU)
     // fp32 maps with a residual branch: the reduction pass writes g = dy * [y > 0] as d residual, the second pass reads it
     // (bf16 maps keep the old form: their dz is computed from the unrounded g)
-    const bool gfirst = relu && !maskz && dres && dz && sizeof(T) == 4 && g_bn_gfirst;
+    const bool gfirst = relu && !maskz && dres && dz && sizeof(T) == 4;
     if (maskz)     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true, true>), rgrid, block, 0, st, R, C, rpc, dy, y, z, mean, invstd, gamma, beta, partial);
     else if (relu && gfirst) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true, false, true>), rgrid, block, 0, st, R, C, rpc, dy, y, z, mean, invstd, gamma, beta, partial, dres);
     else if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true, false>), rgrid, block, 0, st, R, C, rpc, dy, y, z, mean, invstd, gamma, beta, partial);

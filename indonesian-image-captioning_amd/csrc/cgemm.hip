@@ -60,7 +60,6 @@ struct CArgs {
     int S, kper;                  // split-K
     float* ws;
     int mt, nt;                   // tile grid
-    int stagger;                  // start delay (x64 cycles) per residency round of workgroups, see g_cgemm_stagger
     // conv extras
     int gHi, gWi, gHo, gWo, gs;   // row gather (strided 1x1 convolution); gs == 0: none.  3x3: source / destination maps
     int c3c;                      // 3x3 modes: channels per tap of the gathered operand (Cin forward / wgrad, Cout dgrad)
@@ -131,22 +130,6 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = W41 ? wave : wave >> 1, wn = W41 ? 0 : wave & 1;
     const int hh = lane >> 5, l31 = lane & 31;
-
-    // ---- optional start stagger (speed only) ---------------------------------------------------------------------
-    // All workgroups of a launch start together, so co-resident ones fill their rings, run their K loops and store
-    // their tiles in lock-step: the matrix pipe idles chip-wide during fills and stores.  Delaying the second / third
-    // workgroup a CU receives by a fraction of a tile time lets one workgroup's stores overlap another's MFMAs.
-    if (g.stagger > 0) {
-        const int lin = blockIdx.y * gridDim.x + blockIdx.x;
-        int rounds = min(lin >> 8, 2) * g.stagger;
-        while (rounds > 0) {
-            const int n = min(rounds, 127);
-            // s_sleep takes an immediate: 127 / 16 / 1 units compose any count
-            if (n == 127) { __builtin_amdgcn_s_sleep(127); rounds -= 127; }
-            else if (n >= 16) { __builtin_amdgcn_s_sleep(16); rounds -= 16; }
-            else { __builtin_amdgcn_s_sleep(1); rounds -= 1; }
-        }
-    }
 
     // ---- XCD-aware tile order (speed only): blocks b, b+8, b+16 ... share an XCD ---------------------------
     const int ntiles = g.mt * g.nt;
@@ -758,12 +741,9 @@ __global__ __launch_bounds__(256) void cstats_kernel(CArgs g) {
 }  // namespace
 
 constexpr int CG_MAX_SPLIT = 128;   // wgrad of the early layers: 4 output tiles, K = 32768 rows
-int g_cgemm_vec = 1;          // LDS-transposed 16-byte C stores when the output allows it
 int g_cgemm_target = 512;     // aim for this many workgroups (tiles x splits) when the tile grid alone is < 256
 int g_cgemm_kmin = 128;       // at least this much K per split
 int g_cgemm_mi = 0;           // 0: pick the row tile (64 or 128) per shape; 1 / 2: force it (tuning)
-int g_cgemm_w41 = 1;          // 1: outputs at most 64 wide take the 128 x 64 tile with the 4 x 1 wave layout
-int g_cgemm_stagger = 0;      // start delay per residency round, in units of 64 cycles (experiment)
 
 bool cgemm_supported(bool tA, bool tB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                      long sA, long sB) {
@@ -852,7 +832,7 @@ int cgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
             "cgemm: mask epilogue arguments");
     SCN_ARG(pro == 0 || ex->pro_ss, "cgemm: prologue table");
     SCN_ARG(!gather || (ex->Hi > 0 && ex->Wi > 0 && ex->Ho > 0 && ex->Wo > 0 && batch == 1), "cgemm: gather geometry");
-    const bool vec = g_cgemm_vec && N % 4 == 0 && ldc % 4 == 0 && sC % 4 == 0 && aligned16(C) &&
+    const bool vec = N % 4 == 0 && ldc % 4 == 0 && sC % 4 == 0 && aligned16(C) &&
                      ((long)(M - 1) * ldc + N) * 4 < 0x7fffffffL && (long)M * N * 4 < 0x7fffffffL;
     SCN_ARG(epi == 0 || vec, "cgemm: the statistics epilogues need N % 4 == 0, ldc % 4 == 0 and a 16-byte aligned C");
     // row tile: 64 rows when the 128-row grid alone cannot give every CU a workgroup but the 64-row grid can come closer
@@ -861,7 +841,7 @@ int cgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
     // stride-2 d input: the four classes carry 1 / 2 / 2 / 4 taps, so the grid is uneven by construction; 64-row tiles
     // (twice the workgroups, all resident at once) let the dispatcher even it out when the 128-row grid is small
     if (c3 == 4 && (long)cdiv(M, 128) * cdiv(N, TN) * 4 < 768) mi = 1;
-    if (N <= 64 && M >= 128 && g_cgemm_w41 && c3 != 3) mi = 4;     // 128 x 64 tiles, waves 4 x 1 (layer1's 64-channel maps)
+    if (N <= 64 && M >= 128 && c3 != 3) mi = 4;     // 128 x 64 tiles, waves 4 x 1 (layer1's 64-channel maps)
     if (g_cgemm_mi == 1 || g_cgemm_mi == 2) mi = g_cgemm_mi;
     if (ex && ex->force_mi > 0) mi = ex->force_mi;
     SCN_ARG(mi == 1 || mi == 2 || (mi == 4 && c3 != 3), "cgemm: bad tile selector");
@@ -915,7 +895,6 @@ int cgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.rowmask = rowmask;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = sA; g.sB = sB; g.sC = sC;
     g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta; g.S = S; g.kper = kper; g.ws = ws; g.mt = mt; g.nt = nt;
-    g.stagger = g_cgemm_stagger;
     if (ex) {
         g.gHi = ex->Hi; g.gWi = ex->Wi; g.gHo = ex->Ho; g.gWo = ex->Wo; g.gs = (gather || c3) ? ex->stride : 0;
         g.c3c = ex->c3c; g.src_rows = ex->c3_src_rows;

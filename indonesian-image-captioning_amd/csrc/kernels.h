@@ -77,12 +77,6 @@ int attn_scores(hipStream_t st, int rows, int P, int A, const void* att1, Slabs 
 int attn_context(hipStream_t st, int rows, int P, int E, const void* enc, const float* e, Slabs gpre,
                  const float* bbeta, float* alpha_out, long alpha_ld, float* alpha_save, float* awe,
                  float* gate, float* z, bool bf = false);
-// scores + softmax + context + gate in ONE launch (sequence path); attn_fused_ok() says whether the shape
-// qualifies (16-byte alignment, LDS budget), otherwise use attn_scores + attn_context
-bool attn_fused_ok(int P, int E, int A, const float* enc, const float* att1);
-int attn_fused(hipStream_t st, int rows, int P, int E, int A, const float* enc, const float* att1, Slabs att2,
-               const float* bd, const float* wf, const float* b0, Slabs gpre, const float* bbeta, float* alpha_out,
-               long alpha_ld, float* alpha_save, float* att2_out, float* awe, float* gate, float* z);
 int mean_pixels(hipStream_t st, int rows, int P, int E, const float* enc, float* out);
 // dalpha[b,p] = enc[b,p,:] . dawe[b,:] + dalpha_in[b,p]
 // Pooled path (include/scnattn.h, scnattn_pool): encoder_out = fixed linear pooling of x [B][Q][E]
@@ -97,13 +91,6 @@ struct PoolDesc {
 int attn_context_pooled(hipStream_t st, int rows, int P, int E, const void* x, const PoolDesc& pool, const float* e,
                         Slabs gpre, const float* bbeta, float* alpha_out, long alpha_ld, float* alpha_save,
                         float* alphaq_save, float* awe, float* gate, float* z, bool bf = false);
-// scores + softmax + pooled context + gate in one launch (in-launch hand-off of the scores between the E-chunk
-// workgroups of a batch row); e_buf [rows][P], cnt [rows] (zeroed once per sequence), errflag [1]; step = decode step
-bool attn_handoff_ok(int rows, int P, int E, int A, const float* x, const float* att1, const PoolDesc& pool);
-int attn_handoff(hipStream_t st, int rows, int P, int E, int A, int step, const float* x, const float* att1,
-                 const PoolDesc& pool, Slabs att2, const float* bd, const float* wf, const float* b0, Slabs gpre,
-                 const float* bbeta, float* e_buf, int* cnt, int* errflag, float* alpha_out, long alpha_ld,
-                 float* alpha_save, float* alphaq_save, float* att2_out, float* awe, float* gate, float* z);
 int weighted_rows(hipStream_t st, int rows, int Q, int E, const float* x, const float* wts, float* out);
 int attn_softmax_bwd_pooled(hipStream_t st, int rows, int P, int A, const void* att1, const float* att2, const float* w,
                             const float* alpha, const PoolDesc& pool, const float* dalphaq, const float* dalpha_in,

@@ -23,14 +23,6 @@ namespace scn {
 
 int g_ksplit_scale = 0;  // 0 = auto; >0 forces ksplit for every skinny launch (tuning/testing)
 int g_profile = 0;       // 1: bracket the recurrence loops with HIP events (scnattn_profile_collect)
-int g_chains = 1;        // 2: the recurrence runs as two independent half-batch chains (rows are independent
-                         //    inside the loop) on two streams fed by two host threads.  Bit-identical, but
-                         //    measured SLOWER (52.8 vs 47.8 us/step): the step kernels are latency-bound, a
-                         //    half-batch launch takes as long as a full one (attn_context 15.1 vs 14.1 us)
-int g_fuse_attn = 0;     // 1: scores+softmax+context+gate as one launch (measured SLOWER: 54.0 vs 47.5 us/step,
-                         //    each E-chunk workgroup recomputes all 196 scores through its CU's L2 port)
-extern int g_attn_handoff;   // 1: pooled path runs scores + context as one launch with an in-launch hand-off (default 0: not faster)
-int g_handoff_check = 0;     // 1: seq_fwd synchronises at its end and reports a hand-off time-out (tests)
 int g_dec_bf16 = 0;          // 1 (2: + bf16 matrix instruction in the skinny GEMMs): BASELINE configs[4] flavour -- the operands the recurrence STREAMS every step (recurrent
                              //    weights, att1, the encoder map) are kept as bf16 copies, made once per call; products
                              //    accumulate in fp32, softmax / LSTM state / master weights / every gradient stay fp32
@@ -99,7 +91,7 @@ struct Saved {
 constexpr long GEMM_WS_FLOATS = 24L << 20;  // 96 MiB of split-K partials for the big GEMMs (d fc.weight: 4 slabs of 10000 x 512)
 
 struct FwdScratch {
-    float *WcatA, *WD, *slabA, *e, *slabC, *xcat, *slabD, *gws, *y, *cnt;
+    float *WcatA, *WD, *slabA, *e, *slabC, *xcat, *slabD, *gws, *y;
     float *WcatAh, *WDh, *WaMh;      // bf16 copies of the per-step weight operands
 };
 
@@ -154,7 +146,6 @@ size_t carve_fwd(const scnattn_dims& d, int Q, float* base, FwdScratch& s) {
     s.slabD = c.take(sz(SCN_MAX_KSPLIT, 4, B, D));
     s.gws = c.take(GEMM_WS_FLOATS);
     s.y = (d.has_att && Q > 0) ? c.take(sz(B, Q, d.A)) : nullptr;
-    s.cnt = (d.has_att && Q > 0) ? c.take(sz(B + 1)) : nullptr;    // hand-off counters [B] + time-out flag [1] (ints)
     s.WcatAh = c.take((sz(D, NA) + 1) / 2);
     s.WDh = c.take((sz(4, 2 * F, D) + 1) / 2);
     s.WaMh = d.has_att ? c.take((sz(d.E, 4 * F) + 1) / 2) : nullptr;
@@ -252,69 +243,14 @@ inline int pick(int rows, int N, int K, int groups) {
 
 }  // namespace
 
-// ---- two-chain execution of a recurrence ---------------------------------------------------------
-// Inside the time loop no kernel mixes batch rows, so rows [0,r0) and [r0,B) are two independent
-// dependency chains.  Chain 0 is enqueued on the caller's stream by the calling thread, chain 1 on a
-// cached non-blocking side stream by a helper thread (one host thread sustains ~3 us per launch, two
-// threads on two streams ~1.5 us aggregate: tools/launch_rate.hip); fork/join are HIP events, so the
-// caller still sees one asynchronous call ordered on its own stream.  Per-row arithmetic does not
-// depend on the split: results are bit-identical to the single-chain order.
+// The recurrence bodies are written as a function of (stream, first row, row count).  Round 1 ran them as two
+// independent half-batch chains on two streams (no kernel of the loop mixes batch rows); bit-identical but SLOWER (52.8
+// vs 47.8 us per step: the step kernels are latency-bound, a half-batch launch takes as long as a full one), so since
+// round 3 there is one chain on the caller's stream and the machinery is gone (DESIGN.md 6 keeps the numbers).
 namespace {
 
-constexpr int MAX_DEVICES = 16;
-std::mutex g_side_mu;
-hipStream_t g_side[MAX_DEVICES][2] = {};
-
-int side_stream(int kind, hipStream_t* out) {
-    int dev = 0;
-    SCN_HIP(hipGetDevice(&dev));
-    SCN_ARG(dev >= 0 && dev < MAX_DEVICES, "device index out of range");
-    std::lock_guard<std::mutex> lk(g_side_mu);
-    if (!g_side[dev][kind]) SCN_HIP(hipStreamCreateWithFlags(&g_side[dev][kind], hipStreamNonBlocking));
-    *out = g_side[dev][kind];
-    return 0;
-}
-
-// first row of chain 1: half the batch rounded up to 4 rows so every row offset stays 16-byte aligned
-inline int split_row(int B) {
-    if (g_chains < 2) return B;
-    const int r0 = ((B + 1) / 2 + 3) & ~3;
-    return r0 < B ? r0 : B;
-}
-
 template <class Body>   // body(stream, first_row, max_rows) -> 0 or error code
-int run_chains(hipStream_t st, int kind, int B, Body&& body) {
-    const int r0 = split_row(B);
-    if (r0 >= B) return body(st, 0, B);
-    hipStream_t side = nullptr;
-    SCN_TRY(side_stream(kind, &side));
-    int dev = 0;
-    SCN_HIP(hipGetDevice(&dev));
-    hipEvent_t fork = nullptr, join = nullptr;
-    SCN_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-    SCN_HIP(hipEventCreateWithFlags(&join, hipEventDisableTiming));
-    SCN_HIP(hipEventRecord(fork, st));
-    SCN_HIP(hipStreamWaitEvent(side, fork, 0));
-    int rc1 = 0;
-    std::string err1;
-    std::thread helper([&] {
-        if (hipSetDevice(dev) != hipSuccess) { rc1 = -2; err1 = "hipSetDevice failed in chain thread"; return; }
-        rc1 = body(side, r0, B - r0);
-        if (rc1) err1 = last_error();
-    });
-    const int rc0 = body(st, 0, r0);
-    helper.join();
-    // join even after an error so the caller's stream stays ordered after everything that was enqueued
-    const hipError_t e1 = hipEventRecord(join, side);
-    const hipError_t e2 = hipStreamWaitEvent(st, join, 0);
-    (void)hipEventDestroy(fork);
-    (void)hipEventDestroy(join);
-    if (rc0) return rc0;
-    if (rc1) { set_error("%s", err1.c_str()); return rc1; }
-    SCN_HIP(e1);
-    SCN_HIP(e2);
-    return 0;
-}
+int run_chains(hipStream_t st, int /*kind*/, int B, Body&& body) { return body(st, 0, B); }
 
 }  // namespace
 
@@ -406,8 +342,6 @@ int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
 
     // ---- the recurrence --------------------------------------------------------------------------
     const long BD = (long)B * D;
-    const bool handoff = !bf && d.has_att && Q > 0 && attn_handoff_ok(B, P, E, A, enc, s.att1, pd);
-    if (handoff) SCN_HIP(hipMemsetAsync(f.cnt, 0, sizeof(int) * (B + 1), st));
     hipEvent_t ev0 = prof_begin(st);
     SCN_TRY(run_chains(st, 0, B, [&](hipStream_t cs, int r0, int rmax) -> int {
         const void* enc_c = eoff(enc_s, (long)r0 * (Q > 0 ? Q : P) * E, bf && d.has_att);
@@ -430,17 +364,7 @@ int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
             Slabs pz{nullptr, 0, 0, 0};
             if (d.has_att) {
                 float* alpha_out = alphas + (long)r0 * T * P + (long)t * P;
-                if (handoff) {
-                    hipEvent_t evc = g_profile >= 2 ? prof_begin(cs) : nullptr;
-                    int* cnt = reinterpret_cast<int*>(f.cnt);
-                    SCN_TRY(attn_handoff(cs, bt_, P, E, A, t, (const float*)enc_c, (const float*)att1_c, pd, Slabs{slabA, ksA, (long)B * NA, NA},
-                                         w->attention_decoder_att_bias, w->attention_full_att_weight,
-                                         w->attention_full_att_bias, Slabs{slabA + A, ksA, (long)B * NA, NA},
-                                         w->f_beta_bias, e_c, cnt + r0, cnt + B, alpha_out, (long)T * P,
-                                         s.alpha_tm + rowT * P, s.alphaq_tm + rowT * Q, s.att2_all + rowT * A,
-                                         s.awe_all + rowT * E, s.gate_all + rowT * E, s.z_all + rowT * E));
-                    prof_end(cs, evc, 2, 1);
-                } else if (Q > 0) {
+                if (Q > 0) {
                     SCN_TRY(attn_scores(cs, bt_, P, A, att1_c, Slabs{slabA, ksA, (long)B * NA, NA},
                                         w->attention_decoder_att_bias, w->attention_full_att_weight,
                                         w->attention_full_att_bias, e_c, s.att2_all + rowT * A, bf));
@@ -449,15 +373,6 @@ int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
                                                 w->f_beta_bias, alpha_out, (long)T * P, s.alpha_tm + rowT * P,
                                                 s.alphaq_tm + rowT * Q, s.awe_all + rowT * E, s.gate_all + rowT * E,
                                                 s.z_all + rowT * E, bf));
-                    prof_end(cs, evc, 2, 1);
-                } else if (!bf && g_fuse_attn && attn_fused_ok(P, E, A, (const float*)enc_c, (const float*)att1_c)) {
-                    hipEvent_t evc = g_profile >= 2 ? prof_begin(cs) : nullptr;
-                    SCN_TRY(attn_fused(cs, bt_, P, E, A, (const float*)enc_c, (const float*)att1_c, Slabs{slabA, ksA, (long)B * NA, NA},
-                                       w->attention_decoder_att_bias, w->attention_full_att_weight,
-                                       w->attention_full_att_bias, Slabs{slabA + A, ksA, (long)B * NA, NA},
-                                       w->f_beta_bias, alpha_out, (long)T * P, s.alpha_tm + rowT * P,
-                                       s.att2_all + rowT * A, s.awe_all + rowT * E, s.gate_all + rowT * E,
-                                       s.z_all + rowT * E));
                     prof_end(cs, evc, 2, 1);
                 } else {
                     SCN_TRY(attn_scores(cs, bt_, P, A, att1_c, Slabs{slabA, ksA, (long)B * NA, NA},
@@ -492,12 +407,6 @@ int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
     SCN_TRY(hidden_to_bm(st, B, T, D, dl_dev, s.Hs + BD, drop_mask, s.Hd_bm, s.rowmask));
     SCN_TRY(sgemm_ws(st, false, true, B * T, d.V, D, 1.f, s.Hd_bm, D, w->fc_weight, D, 0.f, preds, d.V, w->fc_bias,
                   s.rowmask, 1, 0, 0, 0, f.gws, GEMM_WS_FLOATS));
-    if (handoff && g_handoff_check) {
-        int flag = 0;
-        SCN_HIP(hipMemcpyAsync(&flag, reinterpret_cast<int*>(f.cnt) + B, sizeof(int), hipMemcpyDeviceToHost, st));
-        SCN_HIP(hipStreamSynchronize(st));
-        SCN_ARG(flag == 0, "attention hand-off timed out (a chunk workgroup of a batch row never arrived)");
-    }
     return 0;
 }
 

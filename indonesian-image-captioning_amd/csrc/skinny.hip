@@ -181,8 +181,6 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
 
 }  // namespace
 
-int g_skinny_tail = 1;
-
 int skinny_pick_ksplit(int rows, int N, int K, int groups) {
     const int wgs = cdiv(N, 32) * groups * cdiv(rows > 0 ? rows : 1, 32);
     int ks = cdiv(K, 4 * KW);                // one chunk per wave: every load in flight at once
@@ -192,8 +190,8 @@ int skinny_pick_ksplit(int rows, int N, int K, int groups) {
     if (ks > kmax) ks = kmax;
     // A grid just over one workgroup per CU (257 .. 383) makes a few CUs run two workgroups' matrix chains back to back
     // while the rest idle: the kernel then lasts two chains.  Twice the slices, each half as long, end sooner
-    // (h -> [att2|gpre|ph], 288 workgroups: 6.1 -> 5.3 us stand-alone, option "skinny_tail" 0 restores the old rule).
-    if (g_skinny_tail && (long)wgs * ks > 256 && (long)wgs * ks < 384 && ks * 2 <= kmax) ks *= 2;
+    // (h -> [att2|gpre|ph], 288 workgroups: 6.1 -> 5.3 us stand-alone).
+    if ((long)wgs * ks > 256 && (long)wgs * ks < 384 && ks * 2 <= kmax) ks *= 2;
     if (ks > SCN_MAX_KSPLIT) ks = SCN_MAX_KSPLIT;
     if (ks < 1) ks = 1;
     return ks;

@@ -93,9 +93,6 @@ _SIGS = {
     "scnattn_skinny_gemm_bf16": ([vp, i32, i32, i32, i32, vp, i64, i64, vp, i64, i64, vp, i64, i64, i64, i32,
                                   C.POINTER(i32)], i32),
     "scnattn_f32_to_bf16": ([vp, i64, vp, vp], i32),
-    "scnattn_stream_priority_range": ([C.POINTER(i32), C.POINTER(i32)], i32),
-    "scnattn_stream_create": ([i32, C.POINTER(vp)], i32),
-    "scnattn_stream_destroy": ([vp], i32),
     "scnattn_attn_scores": ([vp, i32, i32, i32, vp, vp, i32, i64, i64, vp, vp, vp, vp, vp], i32),
     "scnattn_attn_context": ([vp, i32, i32, i32, vp, vp, vp, i32, i64, i64, vp, vp, i64, vp, vp, vp, vp], i32),
     "scnattn_mean_pixels": ([vp, i32, i32, i32, vp, vp], i32),

@@ -209,22 +209,6 @@ def _as4d(t2, n, h, w):
     return t2.view(n, h, w, t2.shape[1]).permute(0, 3, 1, 2)
 
 
-class _Ctx:
-    pass
-
-
-SIDE_WGRAD_TARGET = int(os.environ.get("SCNATTN_SIDE_WGRAD_TARGET", "0"))   # experiment: workgroups a side-stream wgrad aims for
-
-
-def _wgrad_split(on_side, M, N, K):
-    """force_split for a weight-gradient product dW [M][N] over K rows when it runs on the side stream and
-    SIDE_WGRAD_TARGET is set: fewer, longer workgroups leave the main stream's convolutions more residency slots."""
-    if not (on_side and SIDE_WGRAD_TARGET > 0):
-        return 0
-    tiles = -(-M // 64) * -(-N // 128)
-    return max(1, min(SIDE_WGRAD_TARGET // max(tiles, 1), max(1, K // 128), 128))
-
-
 def _conv_fwd(h, st, x2, w2, R, Cin, Cout, ws, ex):
     y = torch.empty((R, Cout), device=x2.device, dtype=torch.float32)
     _chk(h.scnattn_conv1x1_fwd(st, R, Cin, Cout, x2.data_ptr(), w2.data_ptr(), y.data_ptr(), C.byref(ex), ws.data_ptr(),
@@ -419,7 +403,7 @@ class _BottleneckFn(torch.autograd.Function):
         dw3 = None
         if need[8]:
             dw3 = _grad_out(w3)
-            ex = ConvExtra(pro=2, pro_ss=ss2.data_ptr(), force_split=_wgrad_split(side is not None, C4, p, Rout))
+            ex = ConvExtra(pro=2, pro_ss=ss2.data_ptr())
             sw, wsw = (side.fork(main, dz3, z2, ss2, dw3), side.ws) if side else (st, ws)
             _chk(h.scnattn_conv1x1_wgrad(sw, Rout, p, C4, dz3.data_ptr(), z2.data_ptr(), dw3.data_ptr(), C.byref(ex),
                                          wsw.data_ptr(), wsw.numel()), "scnattn_conv1x1_wgrad")
@@ -471,7 +455,7 @@ class _BottleneckFn(torch.autograd.Function):
         if need[2]:
             dw1 = _grad_out(w1)
             sw, wsw = (side.fork(main, dz1, x, dw1), side.ws) if side else (st, ws)
-            ex1 = ConvExtra(force_split=_wgrad_split(side is not None, p, Cin, Rin))
+            ex1 = ConvExtra()
             _chk(h.scnattn_conv1x1_wgrad(sw, Rin, Cin, p, dz1.data_ptr(), x2.data_ptr(), dw1.data_ptr(), C.byref(ex1),
                                          wsw.data_ptr(), wsw.numel()), "scnattn_conv1x1_wgrad")
         # ---- identity branch and d x --------------------------------------------------------------------------------

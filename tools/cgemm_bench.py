@@ -414,30 +414,6 @@ def ab():
         print("%-9s | %s | %s | %s | %s | %s" % (name, fmt(f), fmt(d), fmt(g), fmt(tf), fmt(tw)), flush=True)
 
 
-def stagger():
-    """Start-stagger experiment (option cgemm_stagger, units of 64 cycles per residency round): 1x1 forward with both
-    BatchNorm fusions and plain dgrad on the trunk's shapes."""
-    shapes = [("l1.conv1", 131072, 256, 64), ("l1.conv3", 131072, 64, 256), ("l2.conv1", 32768, 512, 128),
-              ("l2.conv3", 32768, 128, 512), ("l3.conv1", 8192, 1024, 256), ("l3.conv3", 8192, 256, 1024),
-              ("l4.conv1", 2048, 2048, 512), ("l4.conv3", 2048, 512, 2048), ("sq4096", 4096, 4096, 4096)]
-    vals = (0, 16, 32, 64, 128, 256)
-    print("%-9s | fwd(pro+epi) at stagger %s | dgrad at the same" % ("layer", vals))
-    for name, R, Cin, Cout in shapes:
-        x = torch.randn(R, Cin, device=dev); w = torch.randn(Cout, Cin, device=dev) * 0.1; y = torch.empty(R, Cout, device=dev)
-        dy = torch.randn(R, Cout, device=dev); dx = torch.empty(R, Cin, device=dev)
-        ss = torch.rand(Cin, 2, device=dev)
-        part = torch.empty(2, max(Cin, Cout), lib().scnattn_cgemm_stat_ld(R), device=dev)
-        ex_b = ConvExtra(pro=1, epi=1, pro_ss=ss.data_ptr(), stat_partial=part.data_ptr())
-        f, d = [], []
-        for v in vals:
-            SF.set_option("cgemm_stagger", v)
-            f.append(t_us(lambda: cgemm(x, w, False, True, y, R, Cout, Cin, ex_b)))
-            d.append(t_us(lambda: cgemm(dy, w, False, False, dx, R, Cin, Cout)))
-        SF.set_option("cgemm_stagger", 0)
-        fmt = lambda l: " ".join("%6.1f" % q for q in l)
-        print("%-9s | %s | %s" % (name, fmt(f), fmt(d)), flush=True)
-
-
 def sweep3():
     """3x3 forward (with the statistics epilogue, as the block issues it) and dgrad: row tile x split-K factor."""
     combos = [(2, 4), (2, 2), (1, 2), (1, 1), (4, 1), (4, 2), (4, 3), (4, 4)]
@@ -533,8 +509,6 @@ if __name__ == "__main__":
         globals()["gemmsweep"]()
     if what == "sweep3":
         sweep3()
-    if what == "stagger":
-        stagger()
     if what in ("check", "all"):
         check()
     if what in ("time", "all"):
