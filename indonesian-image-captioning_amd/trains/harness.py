@@ -177,7 +177,8 @@ class TrainStep:
             feat = prepool if prepool is not None else encoder_out
             if feat.requires_grad:       # fires when the decoder's backward pass hands d(feature map) to the encoder's
                 feat.register_hook(lambda g_, e=ev[2]: (e.record(), None)[1])
-            if self.tagger is not None and tag_event is None:
+        if self.tagger is not None and tag_event is None:       # in line, after the caption encoder (no overlap)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.encoder_bf16):
                 tags = self.tagger(imgs)
         if self.tagger is not None and tag_event is None:
             tags = tags.float()

@@ -1,7 +1,12 @@
 """Worker of tests/test_gpu_parity.py::test_two_process_data_parallel_decoder_step (not a test module).
 One process per rank, all on cuda:0 (RCCL refuses two ranks on one device, so the collective backend is
 gloo; the HIP path, the autograd hooks, the buckets and the 1/world scale are the product's).
-usage: dp_gpu_worker.py RANK WORLD PORT OUTDIR"""
+usage: dp_gpu_worker.py RANK WORLD PORT OUTDIR [dec|enc]
+  dec (default): decoder only, the global batch split over the ranks -> the scaled 2-rank gradient equals the whole-batch one;
+  enc: ResNet-152 fine-tune + decoder, EVERY rank on the SAME batch (BatchNorm statistics are per rank, so only identical
+       data gives identical local gradients): exercises the CUDA branch of GradReducer with the trunk's in-place flat
+       weight gradients -- bucket gather + all-reduce on the side stream that also carries the weight-gradient kernels --
+       and must reproduce the 1-rank flat gradient buffers bit for bit ((g + g) / 2 == g)."""
 import os
 import sys
 
@@ -13,11 +18,41 @@ import torch.distributed as dist  # noqa: E402
 
 def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    mode = sys.argv[5] if len(sys.argv) > 5 else "dec"
     if world > 1:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
         dist.init_process_group("gloo", rank=rank, world_size=world)
     from trains.harness import TrainStep, synthetic_batch
     dev = torch.device("cuda:0")
+    if mode == "enc":
+        ts = TrainStep(kind="attention_scn", fine_tune_encoder=True, device=dev, encoder=True, bucket_mb=8, seed=77,
+                       emb_dim=32, attention_dim=24, decoder_dim=32, factored_dim=40, semantic_dim=12, vocab_size=60,
+                       dropout=0.0, max_len=6, batch_size=4, image_size=64)
+        imgs, tags, caps, caplens = synthetic_batch(4, 60, 6, 64, 12, dev, 5)
+        flats = [ts.decoder_optimizer.flat, ts.encoder_optimizer.flat]
+        out_g = []
+        for rep in range(2):           # second round: warm side stream, reused allocator blocks
+            prepool = ts.encoder(imgs, pooled=False)
+            scores, caps_sorted, dl, alphas, _ = ts.decoder(None, tags, caps, caplens, prepool=prepool, pool_size=14)
+            loss = ts.loss_fn(scores, caps_sorted, dl, alphas)
+            for o in (ts.decoder_optimizer, ts.encoder_optimizer):
+                o.zero_grad()
+            for r in ts.reducers:
+                r.reset()
+            loss.backward()
+            fired = [sum(r.launched) if r.enabled else 0 for r in ts.reducers]
+            scale = 1.0
+            for r in ts.reducers:
+                scale = r.finish()
+            for f in flats:
+                f.gather()
+            torch.cuda.synchronize()
+            out_g = [(f.flat_g * scale).cpu() for f in flats]
+        torch.save({"grads": out_g, "loss": float(loss), "fired": fired, "buckets": [len(r.buckets) for r in ts.reducers]},
+                   os.path.join(out, "enc_w%d_r%d.pt" % (world, rank)))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     ts = TrainStep(kind="attention_scn", fine_tune_encoder=False, device=dev, encoder=False, bucket_mb=0, seed=77 + rank,
                    emb_dim=32, attention_dim=24, decoder_dim=32, factored_dim=40, semantic_dim=12, vocab_size=60,
                    dropout=0.0, max_len=6)                 # different seeds: the broadcast must align the ranks

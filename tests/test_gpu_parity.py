@@ -846,6 +846,43 @@ def test_two_process_data_parallel_decoder_step(dev, tmp_path):
         assert rel_l2(a, b) <= 2e-5, "%s: 2-rank gradient differs from the whole-batch gradient" % name
 
 
+@pytest.mark.gpu
+def test_two_process_data_parallel_encoder_buckets_on_the_side_stream(dev, tmp_path):
+    """ADVICE r02 (dp.py:117): the CUDA branch of GradReducer with MORE than one rank and the fine-tuned trunk in the
+    step -- in-place flat weight gradients produced on the side stream, bucket gather + all-reduce enqueued on that
+    same stream from post-accumulate hooks, join only in finish().  Two processes on this GPU (gloo collectives) run
+    the SAME batch, so their local gradients are identical and the reduced, scaled flat gradient buffers of decoder and
+    encoder must equal the single-process ones bit for bit; every bucket fires during backward."""
+    import socket
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(__file__), "dp_gpu_worker.py")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    env = dict(os.environ)
+    single = subprocess.run([sys.executable, worker, "0", "1", port, str(tmp_path), "enc"], env=env, capture_output=True,
+                            text=True, timeout=600)
+    assert single.returncode == 0, single.stderr[-2000:]
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, str(tmp_path), "enc"], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    for pr in procs:
+        out, err = pr.communicate(timeout=600)
+        assert pr.returncode == 0, err[-2000:]
+    one = torch.load(str(tmp_path / "enc_w1_r0.pt"))
+    r0 = torch.load(str(tmp_path / "enc_w2_r0.pt"))
+    r1 = torch.load(str(tmp_path / "enc_w2_r1.pt"))
+    assert r0["buckets"][1] >= 10 and r0["fired"] == r0["buckets"] == r1["fired"], (r0["buckets"], r0["fired"])
+    assert abs(r0["loss"] - one["loss"]) <= 1e-6 * abs(one["loss"])
+    for which in (0, 1):
+        assert float(one["grads"][which].abs().max()) > 0
+        assert torch.equal(r0["grads"][which], r1["grads"][which]), "ranks disagree after the all-reduce"
+        assert torch.equal(r0["grads"][which], one["grads"][which]), \
+            "2-rank flat gradient (%s) differs from the 1-rank one: max abs %.3e" % \
+            ("decoder" if which == 0 else "encoder", (r0["grads"][which] - one["grads"][which]).abs().max().item())
+
+
 @pytest.mark.parametrize("B,T,V,P,lens,with_alpha", [
     (6, 5, 40, 9, [5, 5, 4, 3, 3, 1], True),        # ragged, V % 4 == 0
     (4, 7, 37, 16, [7, 6, 2, 1], True),             # V % 4 != 0: scalar path

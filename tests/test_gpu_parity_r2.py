@@ -511,6 +511,16 @@ def test_fused_bottleneck_vs_fp64(dev, name, inplanes, planes, stride, H, small,
             mod.bias.data.normal_(0, 0.2)
             mod.running_mean.normal_(0, 0.1)
             mod.running_var.uniform_(0.8, 1.2)
+    if not small:
+        # Full size (round 3): with ~10^6 activations in front of each ReLU a handful lie within fp32
+        # rounding of 0, and ONE flipped mask bit moves every row of the upstream weight gradients by ~1e-3 (through conv2's d
+        # input it reaches all channels of nine pixels) -- the 1e-2 bar of round 2.  The BatchNorms in front of a ReLU get
+        # beta += 3.5: the mask stays active (0.02 % of the activations are still cut, and they vary over pixels and
+        # channels) but ~500x fewer activations sit within rounding of the threshold, so the fp32 bar (2e-4) holds at full size.
+        with torch.no_grad():
+            m.bn1.bias.add_(3.5)
+            m.bn2.bias.add_(3.5)
+            m.bn3.bias.add_(6.0)      # + identity of either sign (raw input / downsample BatchNorm output): further out
     m.train()
     N = 2 if small else 4
     x = torch.relu(torch.randn(N, inplanes, H, H)) + 0.1 * torch.randn(N, inplanes, H, H)
@@ -552,32 +562,14 @@ def test_fused_bottleneck_vs_fp64(dev, name, inplanes, planes, stride, H, small,
     # bit differs between two equally valid evaluations (fp64 here, fp32 there, MIOpen vs this kernel), and one flipped
     # element moves that channel's d beta / d gamma by O(1/sqrt(rows)) and, through the batch statistics, every row of
     # the channel a little (measured: either path shows 5e-4 .. 1e-3 in l2 against fp64 on some blocks, 1e-6 on others,
-    # with the roles swapping between blocks).  So at full size: l2 within 1e-2 (a structural mistake shows up as
-    # O(0.1 .. 1)) and within 3x the unfused path's own distance from fp64 (+1e-3); at the reduced size, where no
-    # ambiguous bit is expected, 1e-4 (measured 4e-7).  The kernels themselves are held to 3e-6 with masks given (test_cgemm_variants_vs_fp64).
+    # with the roles swapping between blocks).  Round 3: at full size the test makes the masks unambiguous (beta + 3.5
+    # above) and holds every gradient to 2e-4; at the reduced size, where no ambiguous bit is expected anyway, 1e-4
+    # (measured 4e-7).  The kernels themselves are held to 3e-6 with masks given (test_cgemm_variants_vs_fp64).
     def close(got, ref, what):
         if small:      # no ambiguous mask bit expected at this size (deterministic seeds and kernels): fp32 tolerance
             assert rel_l2(got, ref) <= 1e-4, "%s l2 %.3e" % (what, rel_l2(got, ref))
             return
-        # Full size (round 3): a mask flip is a LOCALISED error, a wrong kernel a DENSE one.  One
-        # flipped activation (channel c of pixel r) changes: the d-input map at pixel r and its 3x3 neighbourhood (a few
-        # thousand of ~10^6 elements), and -- through dz[r][c] and that channel's BatchNorm sums -- ROW c of each weight
-        # gradient and element c of d gamma / d beta.  So besides the l2 bound: maps must agree to 1e-4 of their RMS on
-        # 99 % of their elements, weight gradients on 90 % of their rows (output channels), vectors on 90 % of their
-        # elements.  A 1 % systematic error fails these by two orders of magnitude; this is "exclude the elements the
-        # ambiguous mask bits reach, then require 1e-4" without having to know which bits flipped.
-        assert rel_l2(got, ref) <= 1e-2, "%s l2 %.3e" % (what, rel_l2(got, ref))
-        gd, rd = got.detach().double().cpu(), ref.detach().double().cpu()
-        rms = rd.norm().item() / max(rd.numel(), 1) ** 0.5
-        if what == "d x":
-            d, frac = (gd - rd).abs().flatten(), 0.99
-        elif gd.dim() >= 2:       # per output channel: RMS error of the row
-            d, frac = (gd - rd).flatten(1).pow(2).mean(1).sqrt(), 0.90
-        else:
-            d, frac = (gd - rd).abs(), 0.90
-        if d.numel() >= 32:
-            q = d.kthvalue(max(1, int(d.numel() * frac))).values.item() / max(rms, 1e-300)
-            assert q <= 1e-4, "%s: %.0f %% quantile of |err| / rms = %.3e" % (what, 100 * frac, q)
+        assert rel_l2(got, ref) <= 2e-4, "%s l2 %.3e" % (what, rel_l2(got, ref))
     close(dx, xr.grad, "d x")
     for k, p in ref.named_parameters():
         close(gr[k], p.grad, k)
@@ -588,7 +580,7 @@ def test_fused_bottleneck_vs_fp64(dev, name, inplanes, planes, stride, H, small,
             assert int(bufs[k]) == int(b) == 1, k
     # and the fused path is no worse than the unfused one (MIOpen convolutions + separate BN passes)
     yu, dxu, gru, _ = res[False]
-    assert rel_err(y, yr) <= max(2e-6, 3 * rel_err(yu, yr))
+    assert rel_err(y, yr) <= max(1e-5, 3 * rel_err(yu, yr))
     assert rel_l2(dx, xr.grad) <= 1e-3 + 3 * rel_l2(dxu, xr.grad)
 
 
@@ -1064,16 +1056,11 @@ def test_reference_loop_body_with_stock_adam(dev):
 def test_tagger_beside_the_encoder_gives_the_same_step(dev):
     """trains/harness.py: with a tagger in the step (trains/attention_scn.py:194,214) its forward pass runs on the side
     stream beside the caption encoder's (per-stream scratch buffers, event-ordered hand-over of the tags).  Same
-    weights, same batch, against the in-line order.  The comparison cannot be bit-exact: the two trunks then run
-    through different MIOpen handles (one per stream, each with its own find result for the stem and the 3x3 weight
-    gradients), and a randomly initialised 152-layer trunk amplifies a last-bit difference a thousandfold (its OWN
-    run-to-run spread on one stream is 2-4e-4, because the statistics epilogue is shifted by the running mean, which
-    moves every call).  So: losses of two steps within 5e-3, parameters within the 2 * steps * lr of an Adam
-    trajectory, tagger statistics within 1e-3 -- a tag tensor read before it was written, or scratch shared between
-    the two streams, is an O(1) error in the loss."""
+    weights, same batch, against the in-line order: bit-identical since round 3 (see below) -- a tag tensor read before
+    it was written, or scratch shared between the two streams, would be an O(1) error in the loss."""
     from trains.harness import TrainStep, synthetic_batch
     res = {}
-    for overlap in (False, True, True):
+    for overlap in (False, False, True, True):
         ts = TrainStep(device=dev, tagger=True, tagger_overlap=overlap, seed=77, batch_size=4, max_len=8, vocab_size=300,
                        image_size=96)
         cfg = ts.cfg
@@ -1084,17 +1071,25 @@ def test_tagger_beside_the_encoder_gives_the_same_step(dev):
         key = "overlap" if overlap else "inline"
         cur = (losses, {k: p.detach().clone() for k, p in ts.decoder.named_parameters()},
                {k: b.detach().clone() for k, b in ts.tagger.named_buffers() if k.endswith("running_mean")})
-        if key in res:       # second overlapped run: the side stream is warm, buffers are being reused
-            key = "overlap2"
+        if key in res:       # second run of a mode: the side stream is warm, buffers are being reused
+            key = key + "2"
         res[key] = cur
+    rep = ["%s: losses %s" % (k, ["%.6f" % l.item() for l in v[0]]) for k, v in res.items()]
+    _report(rep, "tagger beside the encoder: raw losses")
+    # round 3: no library kernel is left in either trunk, so two runs of the SAME mode are bit-identical
+    for a_, b_ in zip(res["inline"][0], res["inline2"][0]):
+        assert torch.equal(a_, b_), "two in-line runs differ: %r vs %r" % (a_.item(), b_.item())
     rep = []
+    # ... and, every kernel of both trunks being this repository's (fixed summation orders, per-stream scratch), the
+    # overlapped runs reproduce the in-line ones BIT FOR BIT: losses of both steps, every decoder parameter after two Adam
+    # steps, the tagger's running statistics.  (Rounds 1-2 could only ask for 5e-3: MIOpen's per-stream handles picked
+    # different solvers for the two streams.)
     for key in ("overlap", "overlap2"):
         for i, (a_, b_) in enumerate(zip(res["inline"][0], res[key][0])):
             rep.append("%s: loss of step %d  %.6f vs in-line %.6f" % (key, i + 1, b_.item(), a_.item()))
-            _ok(b_, a_, 5e-3, "loss (%s)" % key)
+            assert torch.equal(a_, b_), "loss of step %d (%s): %r vs in-line %r" % (i + 1, key, b_.item(), a_.item())
         for k in res["inline"][1]:
-            err = (res["inline"][1][k] - res[key][1][k]).abs().max().item()
-            assert err <= 2 * 2 * 4e-4 * 1.01, "%s (%s): %.3e" % (k, key, err)
+            assert torch.equal(res["inline"][1][k], res[key][1][k]), "%s (%s) differs from the in-line run" % (k, key)
         for k in res["inline"][2]:
-            assert rel_err(res[key][2][k], res["inline"][2][k]) <= 1e-3, "tagger statistics %s differ (%s)" % (k, key)
+            assert torch.equal(res[key][2][k], res["inline"][2][k]), "tagger statistics %s differ (%s)" % (k, key)
     _report(rep, "tagger forward on the side stream beside the caption encoder vs in line")
