@@ -352,7 +352,8 @@ int scnattn_stem_tiles(int N, int H, int W);
 int scnattn_stem_conv7(void* stream, int N, int H, int W, const float* x, long sn, long sc, long sh, long sw,
                        const float* w, long wn, long wc, long wh, long ww, float* z, float* stat_partial,
                        const float* stat_shift);
-int scnattn_stem_bn_relu_maxpool(void* stream, int N, int Hz, int Wz, int C, const float* z, const float* ss, float* out);
+int scnattn_stem_bn_relu_maxpool(void* stream, int N, int Hz, int Wz, int C, const float* z, const float* ss, void* out,
+                                 int out_bf16);       /* out_bf16 != 0: the pooled map is written as bf16 (mixed-precision trunk) */
 /* ---- BatchNorm statistics that ride on the convolutions, finalized ON LOAD (csrc/batchnorm.hip) --------------------------
  * The statistics epilogues above (and scnattn_stem_conv7, scnattn_bn_bwd_reduce, the dgrad mask pass) leave CHANNEL-MAJOR
  * partials  partial[2][C][ldp]:  entry (which, channel, chunk), ldp = chunk count rounded up to 4
@@ -375,14 +376,48 @@ int scnattn_cgemm_stat_ld(int M);
 int scnattn_bn_finalize(void* stream, long R, int C, const float* partial, int ldp, int nchunk, const float* shift,
                         float eps, float momentum, float* mean, float* invstd, float* run_mean, float* run_var,
                         const float* gamma, const float* beta, float* ss_out);
-int scnattn_bn_apply_fin(void* stream, long R, int C, const float* z, const float* res, const float* partial, int ldp,
+/* bf16 != 0: every MAP argument (z, res, y / dy, y, z, gout / g, z, dz) holds bf16 elements; statistics, partials and
+ * parameters are fp32 either way */
+int scnattn_bn_apply_fin(void* stream, long R, int C, const void* z, const void* res, int bf16, const float* partial, int ldp,
                          int nchunk, const float* shift, float eps, float momentum, const float* gamma, const float* beta,
-                         int relu, float* y, float* mean, float* invstd, float* run_mean, float* run_var, float* ss_out);
-int scnattn_bn_bwd_reduce(void* stream, int R, int C, const float* dy, const float* y, const float* z, const float* mean,
-                          const float* invstd, int relu, float* partial, int ldp_cap, float* gout, int* nchunk_out);
-int scnattn_bn_bwd_dx_fin(void* stream, long R, int C, const float* g, const float* z, const float* mean,
+                         int relu, void* y, float* mean, float* invstd, float* run_mean, float* run_var, float* ss_out);
+int scnattn_bn_bwd_reduce(void* stream, int R, int C, const void* dy, const void* y, const void* z, int bf16, const float* mean,
+                          const float* invstd, int relu, float* partial, int ldp_cap, void* gout, int* nchunk_out);
+int scnattn_bn_bwd_dx_fin(void* stream, long R, int C, const void* g, const void* z, int bf16, const float* mean,
                           const float* invstd, const float* gamma, const float* partial, int ldp, int nchunk, float* dbeta,
-                          float* dgamma, float* dz);
+                          float* dgamma, void* dz);
+
+/* ---- mixed-precision trunk (BASELINE configs[4]): bf16 maps and operand copies, fp32 accumulation / statistics / master
+ * weights / weight gradients (csrc/cgemm16.hip, csrc/wgrad16.hip) ------------------------------------------------------------
+ * The same convolutions of torchvision's Bottleneck (models/encoders/caption.py:17-22) on v_mfma_f32_32x32x16_bf16.
+ *   scnattn_bf16_weights   ONE launch per step: every convolution weight [Cout][taps][Cin] fp32 -> a bf16 copy in the same
+ *                          layout (forward B operand) and a transposed bf16 copy [Cin][taps][Cout] (d-input B operand);
+ *                          desc / tile_prefix are device arrays (tile_prefix[i] = number of 32 x 32 tiles of weights 0..i-1,
+ *                          a weight has taps * Cout/32 * Cin/32 of them; Cout, Cin multiples of 32);
+ *   scnattn_cgemm16        C[M][N] = A[M][K] . B[N][K]^T (+ beta*C): A, B bf16 k-contiguous, C bf16 (out_bf16) or fp32;
+ *                          ex: epi 1 (statistics of C from the fp32 accumulators, channel-major partials), stride (row
+ *                          gather of a strided 1x1 convolution); a 1x1 d input is this with B = the transposed copy;
+ *   scnattn_conv3x3_fwd16 / _dgrad16   implicit GEMMs as in fp32 (taps over K; stride-2 d input by parity classes);
+ *   scnattn_wgrad16_3x3    dw [Cout][3][3][Cin] fp32 of a stride-1 3x3 convolution from bf16 maps: contraction over pixels
+ *                          with both operands read through the transposing LDS load (ds_read_b64_tr_b16), halo staged once;
+ *   scnattn_wgrad16_rows   dw[co][ci] (ldo) = sum_r dy[r][co] * x[src(r)][ci]: 1x1 weight gradients (gs = 0), the strided
+ *                          downsample (gs = stride, goh = gow = 0) and ONE TAP of a stride-2 3x3 (gs = 2, goh = dh - 1,
+ *                          gow = dw - 1, dw offset by tap*Cin, ldo = 9*Cin); Cin, Cout multiples of 64. */
+typedef struct scnattn_weight_desc {
+    const float* src; void* dst; void* dst_t; int cout, taps, cin, pad;
+} scnattn_weight_desc;
+int scnattn_bf16_weights(void* stream, int n, const scnattn_weight_desc* desc, const int* tile_prefix, int total_tiles);
+int scnattn_cgemm16(void* stream, int M, int N, int K, const void* A, long lda, const void* B, long ldb, float beta, void* C,
+                    long ldc, int out_bf16, float* ws, long ws_floats, const scnattn_conv_extra* ex);
+int scnattn_conv3x3_fwd16(void* stream, int N, int Hi, int Wi, int Cin, int Cout, int stride, const void* x, const void* w,
+                          void* y, const scnattn_conv_extra* ex, float* ws, long ws_floats);
+int scnattn_conv3x3_dgrad16(void* stream, int N, int Hi, int Wi, int Cin, int Cout, int stride, const void* dy, const void* wt,
+                            void* dx, float* ws, long ws_floats);
+int scnattn_wgrad16_3x3(void* stream, int N, int H, int W, int Cin, int Cout, const void* dy, const void* x, float* dw,
+                        float* ws, long ws_floats, int k_slices);
+int scnattn_wgrad16_rows(void* stream, int R, int Cin, int Cout, const void* dy, const void* x, long src_rows, float* dw,
+                         long ldo, int gs, int gHi, int gWi, int gHo, int gWo, int goh, int gow, float* ws, long ws_floats,
+                         int k_slices);
 /* scnattn_bn_stats (fp32 maps) that also writes the folded {scale, shift} pairs [C][2] for a consumer's prologue */
 int scnattn_bn_stats_fold(void* stream, int R, int C, const void* x, float eps, float momentum, float* partial,
                           float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma,

@@ -219,8 +219,9 @@ int scnattn_stem_conv7(void* stream, int N, int H, int W, const float* x, long s
     return stem_conv7(ST(stream), N, H, W, x, sn, sc, sh, sw, w, wn, wc, wh, ww, z, stat_partial, stat_shift);
 }
 
-int scnattn_stem_bn_relu_maxpool(void* stream, int N, int Hz, int Wz, int C, const float* z, const float* ss, float* out) {
-    return stem_bn_relu_maxpool(ST(stream), N, Hz, Wz, C, z, ss, out);
+int scnattn_stem_bn_relu_maxpool(void* stream, int N, int Hz, int Wz, int C, const float* z, const float* ss, void* out,
+                                 int out_bf16) {
+    return stem_bn_relu_maxpool(ST(stream), N, Hz, Wz, C, z, ss, out, out_bf16);
 }
 
 int scnattn_cgemm_stat_ld(int M) { return cgemm_stat_ld(M); }
@@ -232,22 +233,70 @@ int scnattn_bn_finalize(void* stream, long R, int C, const float* partial, int l
                          beta, ss_out);
 }
 
-int scnattn_bn_apply_fin(void* stream, long R, int C, const float* z, const float* res, const float* partial, int ldp,
+int scnattn_bn_apply_fin(void* stream, long R, int C, const void* z, const void* res, int bf16, const float* partial, int ldp,
                          int nchunk, const float* shift, float eps, float momentum, const float* gamma, const float* beta,
-                         int relu, float* y, float* mean, float* invstd, float* run_mean, float* run_var, float* ss_out) {
-    return bn_apply_fin(ST(stream), R, C, z, res, partial, ldp, nchunk, shift, eps, momentum, gamma, beta, relu, y, mean,
+                         int relu, void* y, float* mean, float* invstd, float* run_mean, float* run_var, float* ss_out) {
+    return bn_apply_fin(ST(stream), R, C, z, res, bf16, partial, ldp, nchunk, shift, eps, momentum, gamma, beta, relu, y, mean,
                         invstd, run_mean, run_var, ss_out);
 }
 
-int scnattn_bn_bwd_reduce(void* stream, int R, int C, const float* dy, const float* y, const float* z, const float* mean,
-                          const float* invstd, int relu, float* partial, int ldp_cap, float* gout, int* nchunk_out) {
-    return bn_bwd_reduce_t(ST(stream), R, C, dy, y, z, mean, invstd, relu, partial, ldp_cap, gout, nchunk_out);
+int scnattn_bn_bwd_reduce(void* stream, int R, int C, const void* dy, const void* y, const void* z, int bf16, const float* mean,
+                          const float* invstd, int relu, float* partial, int ldp_cap, void* gout, int* nchunk_out) {
+    return bn_bwd_reduce_t(ST(stream), R, C, dy, y, z, bf16, mean, invstd, relu, partial, ldp_cap, gout, nchunk_out);
 }
 
-int scnattn_bn_bwd_dx_fin(void* stream, long R, int C, const float* g, const float* z, const float* mean,
+int scnattn_bn_bwd_dx_fin(void* stream, long R, int C, const void* g, const void* z, int bf16, const float* mean,
                           const float* invstd, const float* gamma, const float* partial, int ldp, int nchunk, float* dbeta,
-                          float* dgamma, float* dz) {
-    return bn_bwd_dx_fin(ST(stream), R, C, g, z, mean, invstd, gamma, partial, ldp, nchunk, dbeta, dgamma, dz);
+                          float* dgamma, void* dz) {
+    return bn_bwd_dx_fin(ST(stream), R, C, g, z, bf16, mean, invstd, gamma, partial, ldp, nchunk, dbeta, dgamma, dz);
+}
+
+// ---- mixed-precision (bf16) convolution path ---------------------------------------------------------------------------------
+int scnattn_cgemm16(void* stream, int M, int N, int K, const void* A, long lda, const void* B, long ldb, float beta, void* C,
+                    long ldc, int out_bf16, float* ws, long ws_floats, const scnattn_conv_extra* ex) {
+    const ConvExtra x = to_extra(ex);
+    return cgemm16(ST(stream), M, N, K, A, lda, B, ldb, beta, C, ldc, out_bf16, ws, ws ? ws_floats : 0, ex ? &x : nullptr, 0);
+}
+
+int scnattn_conv3x3_fwd16(void* stream, int N, int Hi, int Wi, int Cin, int Cout, int stride, const void* x, const void* w,
+                          void* y, const scnattn_conv_extra* ex, float* ws, long ws_floats) {
+    SCN_ARG(N > 0 && Hi > 0 && Wi > 0 && stride >= 1, "conv3x3_fwd16: geometry");
+    ConvExtra e = to_extra(ex);
+    const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
+    e.c3 = 1; e.c3c = Cin; e.c3_src_rows = (long)N * Hi * Wi; e.Hi = Hi; e.Wi = Wi; e.Ho = Ho; e.Wo = Wo; e.stride = stride;
+    return cgemm16(ST(stream), N * Ho * Wo, Cout, 9 * Cin, x, Cin, w, 9L * Cin, 0.f, y, Cout, 1, ws, ws ? ws_floats : 0, &e, 0);
+}
+
+// wt: the TRANSPOSED bf16 weight copy [Cin][3][3][Cout] (scnattn_bf16_weights).  stride 1: a forward convolution of dy with
+// flipped taps; stride 2: four parity classes in one launch.
+int scnattn_conv3x3_dgrad16(void* stream, int N, int Hi, int Wi, int Cin, int Cout, int stride, const void* dy, const void* wt,
+                            void* dx, float* ws, long ws_floats) {
+    SCN_ARG(N > 0 && Hi > 0 && Wi > 0 && (stride == 1 || (stride == 2 && Hi % 2 == 0 && Wi % 2 == 0)), "conv3x3_dgrad16: geometry");
+    ConvExtra e;
+    if (stride == 1) {
+        e.c3 = 1; e.c3c = Cout; e.c3_src_rows = (long)N * Hi * Wi; e.Hi = Hi; e.Wi = Wi; e.Ho = Hi; e.Wo = Wi; e.stride = 1;
+        return cgemm16(ST(stream), N * Hi * Wi, Cin, 9 * Cout, dy, Cout, wt, 9L * Cout, 0.f, dx, Cin, 1, ws, ws ? ws_floats : 0, &e, 1);
+    }
+    const int Ho = Hi / 2, Wo = Wi / 2;
+    e.c3 = 4; e.c3c = Cout; e.c3_src_rows = (long)N * Ho * Wo; e.Hi = Hi; e.Wi = Wi; e.Ho = Ho; e.Wo = Wo; e.stride = 2;
+    return cgemm16(ST(stream), N * Ho * Wo, Cin, 9 * Cout, dy, Cout, wt, 9L * Cout, 0.f, dx, Cin, 1, ws, ws ? ws_floats : 0, &e, 0);
+}
+
+int scnattn_wgrad16_3x3(void* stream, int N, int H, int W, int Cin, int Cout, const void* dy, const void* x, float* dw,
+                        float* ws, long ws_floats, int k_slices) {
+    return wgrad16_3x3(ST(stream), N, H, W, Cin, Cout, dy, x, dw, ws, ws ? ws_floats : 0, k_slices);
+}
+
+int scnattn_wgrad16_rows(void* stream, int R, int Cin, int Cout, const void* dy, const void* x, long src_rows, float* dw,
+                         long ldo, int gs, int gHi, int gWi, int gHo, int gWo, int goh, int gow, float* ws, long ws_floats,
+                         int k_slices) {
+    return wgrad16_rows(ST(stream), R, Cin, Cout, dy, x, src_rows, dw, ldo, gs, gHi, gWi, gHo, gWo, goh, gow, ws,
+                        ws ? ws_floats : 0, k_slices);
+}
+
+int scnattn_bf16_weights(void* stream, int n, const scnattn_weight_desc* desc, const int* tile_prefix, int total_tiles) {
+    static_assert(sizeof(scnattn_weight_desc) == sizeof(WeightDesc), "descriptor layout");
+    return bf16_weights(ST(stream), n, reinterpret_cast<const WeightDesc*>(desc), tile_prefix, total_tiles);
 }
 
 int scnattn_bn_stats_fold(void* stream, int R, int C, const void* x, float eps, float momentum, float* partial,

@@ -299,10 +299,10 @@ struct BnFin {      // what a forward finalize produces besides the normalised m
 // y = [relu](gamma*(z-mean)*invstd + beta [+ res]) with mean / invstd computed here from the producer's partials.
 // grid (C/64 column blocks, row chunks).  `shift` must not alias anything this kernel writes (the caller hands over the
 // PREVIOUS step's batch mean, not the running mean this kernel updates).
-template <bool RELU, bool RES>
-__global__ __launch_bounds__(256) void bn_apply_fin_kernel(long R, int C, int rows_per_chunk, const float* __restrict__ z,
-                                                           const float* __restrict__ res, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float* __restrict__ y, BnFin f) {
+template <typename T, bool RELU, bool RES>
+__global__ __launch_bounds__(256) void bn_apply_fin_kernel(long R, int C, int rows_per_chunk, const T* __restrict__ z,
+                                                           const T* __restrict__ res, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, T* __restrict__ y, BnFin f) {
     __shared__ float st[2][64];
     __shared__ float smu[64], sis[64];
     const int c0 = blockIdx.x * 64;
@@ -314,8 +314,8 @@ __global__ __launch_bounds__(256) void bn_apply_fin_kernel(long R, int C, int ro
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const long off = min(r + 16 * j, r1 - 1) * C + cq;
-        v[j] = *reinterpret_cast<const f32x4*>(z + off);
-        if (RES) rr[j] = *reinterpret_cast<const f32x4*>(res + off);
+        v[j] = IO<T>::ld(z + off);
+        if (RES) rr[j] = IO<T>::ld(res + off);
     }
     reduce_partials_t(f.partial, C, f.ldp, f.nchunk, c0, st);
     if (threadIdx.x < 64 && c0 + threadIdx.x < C) {
@@ -364,13 +364,13 @@ __global__ __launch_bounds__(256) void bn_apply_fin_kernel(long R, int C, int ro
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const long off = min(rn + 16 * j, r1 - 1) * C + c;
-                v[j] = *reinterpret_cast<const f32x4*>(z + off);
-                if (RES) rr[j] = *reinterpret_cast<const f32x4*>(res + off);
+                v[j] = IO<T>::ld(z + off);
+                if (RES) rr[j] = IO<T>::ld(res + off);
             }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (r + 16 * j < r1) *reinterpret_cast<f32x4*>(y + (r + 16 * j) * C + c) = o[j];
+            if (r + 16 * j < r1) IO<T>::st(y + (r + 16 * j) * C + c, o[j]);
         r = rn;
     }
 }
@@ -405,12 +405,13 @@ __global__ __launch_bounds__(256) void bn_finalize_t_kernel(long R, int C, const
 
 // dz = gamma*invstd*(g - dbeta/R - xhat*dgamma/R) from an already masked g, with dbeta = sum g and dgamma = sum g*xhat
 // summed here from the channel-major partials the mask pass / the reduce pass wrote
-__global__ __launch_bounds__(256) void bn_bwd_dx_fin_kernel(long R, int C, int rows_per_chunk, const float* __restrict__ g,
-                                                            const float* __restrict__ z, const float* __restrict__ mean,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_dx_fin_kernel(long R, int C, int rows_per_chunk, const T* __restrict__ g,
+                                                            const T* __restrict__ z, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                             const float* __restrict__ partial, int ldp, int nchunk,
                                                             float* __restrict__ dbeta, float* __restrict__ dgamma,
-                                                            float* __restrict__ dz) {
+                                                            T* __restrict__ dz) {
     __shared__ float st[2][64];
     const int c0 = blockIdx.x * 64;
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4, c = c0 + cl * 4, cq = min(c, C - 4);
@@ -420,8 +421,8 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_fin_kernel(long R, int C, int r
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const long off = min(r + 16 * j, r1 - 1) * C + cq;
-        gg[j] = *reinterpret_cast<const f32x4*>(g + off);
-        zz[j] = *reinterpret_cast<const f32x4*>(z + off);
+        gg[j] = IO<T>::ld(g + off);
+        zz[j] = IO<T>::ld(z + off);
     }
     reduce_partials_t(partial, C, ldp, nchunk, c0, st);
     if (blockIdx.y == 0 && threadIdx.x < 64 && c0 + threadIdx.x < C) {
@@ -447,13 +448,13 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_fin_kernel(long R, int C, int r
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const long off = min(rn + 16 * j, r1 - 1) * C + c;
-                gg[j] = *reinterpret_cast<const f32x4*>(g + off);
-                zz[j] = *reinterpret_cast<const f32x4*>(z + off);
+                gg[j] = IO<T>::ld(g + off);
+                zz[j] = IO<T>::ld(z + off);
             }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (r + 16 * j < r1) *reinterpret_cast<f32x4*>(dz + (r + 16 * j) * C + c) = o[j];      // dz may alias g: same element, read first
+            if (r + 16 * j < r1) IO<T>::st(dz + (r + 16 * j) * C + c, o[j]);      // dz may alias g: same element, read first
         r = rn;
     }
 }
@@ -645,21 +646,26 @@ static inline int ew_chunks(long R, int C, int* rows_per_chunk) {       // ~1024
     return (int)((R + rpc - 1) / rpc);
 }
 
-int bn_apply_fin(hipStream_t st, long R, int C, const float* z, const float* res, const float* partial, int ldp, int nchunk,
-                 const float* shift, float eps, float momentum, const float* gamma, const float* beta, int relu, float* y,
+int bn_apply_fin(hipStream_t st, long R, int C, const void* z, const void* res, int bf16, const float* partial, int ldp, int nchunk,
+                 const float* shift, float eps, float momentum, const float* gamma, const float* beta, int relu, void* y,
                  float* mean, float* invstd, float* run_mean, float* run_var, float* ss_out) {
     SCN_ARG(R > 0 && C > 0 && C % 4 == 0 && z && y && partial && ldp >= nchunk && ldp % 4 == 0 && nchunk > 0 && gamma && beta &&
-            mean && invstd && aligned16(z) && aligned16(y) && aligned16(partial) && (!res || aligned16(res)), "bn_apply_fin: bad argument");
+            mean && invstd && aligned16(partial), "bn_apply_fin: bad argument");
+    SCN_ARG(((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res)) & (bf16 ? 7u : 15u)) == 0,
+            "bn_apply_fin: maps are not vector aligned");
     SCN_ARG(shift != run_mean || !run_mean, "bn_apply_fin: shift must not alias the running mean it updates");
     SCN_ARG(2L * C * ldp * 4 < 0x7fffffffL, "bn_apply_fin: partial too large");
     BnFin f{partial, ldp, nchunk, shift, eps, momentum, mean, invstd, run_mean, run_var, ss_out};
     int rpc;
     const int nch = ew_chunks(R, C, &rpc);
     dim3 grid(cdiv(C, 64), nch), block(256);
-    if (relu && res)  hipLaunchKernelGGL((bn_apply_fin_kernel<true, true>), grid, block, 0, st, R, C, rpc, z, res, gamma, beta, y, f);
-    else if (relu)    hipLaunchKernelGGL((bn_apply_fin_kernel<true, false>), grid, block, 0, st, R, C, rpc, z, res, gamma, beta, y, f);
-    else if (res)     hipLaunchKernelGGL((bn_apply_fin_kernel<false, true>), grid, block, 0, st, R, C, rpc, z, res, gamma, beta, y, f);
-    else              hipLaunchKernelGGL((bn_apply_fin_kernel<false, false>), grid, block, 0, st, R, C, rpc, z, res, gamma, beta, y, f);
+#define SCN_AF(T_, RELU_, RES_) hipLaunchKernelGGL((bn_apply_fin_kernel<T_, RELU_, RES_>), grid, block, 0, st, R, C, rpc, (const T_*)z, (const T_*)res, gamma, beta, (T_*)y, f)
+    if (bf16) {
+        if (relu && res) SCN_AF(__bf16, true, true); else if (relu) SCN_AF(__bf16, true, false); else if (res) SCN_AF(__bf16, false, true); else SCN_AF(__bf16, false, false);
+    } else {
+        if (relu && res) SCN_AF(float, true, true); else if (relu) SCN_AF(float, true, false); else if (res) SCN_AF(float, false, true); else SCN_AF(float, false, false);
+    }
+#undef SCN_AF
     SCN_LAUNCH_CHECK();
     return 0;
 }
@@ -679,8 +685,8 @@ int bn_finalize_t(hipStream_t st, long R, int C, const float* partial, int ldp, 
 
 // g = dy * [y > 0] (relu with the forward output y) or dy; sums of g and g*xhat as channel-major partials [2][C][ldp];
 // g is written to gout (it is the residual branch's gradient).  Returns the chunk count through nchunk_out.
-int bn_bwd_reduce_t(hipStream_t st, int R, int C, const float* dy, const float* y, const float* z, const float* mean,
-                    const float* invstd, int relu, float* partial, int ldp_cap, float* gout, int* nchunk_out) {
+int bn_bwd_reduce_t(hipStream_t st, int R, int C, const void* dy, const void* y, const void* z, int bf16, const float* mean,
+                    const float* invstd, int relu, float* partial, int ldp_cap, void* gout, int* nchunk_out) {
     SCN_ARG(R > 0 && C > 0 && C % 4 == 0 && dy && z && mean && invstd && partial && (!relu || y), "bn_bwd_reduce_t: bad argument");
     int rpc;
     const int nchunk = pick_chunks(R, C, &rpc);
@@ -688,23 +694,28 @@ int bn_bwd_reduce_t(hipStream_t st, int R, int C, const float* dy, const float* 
     SCN_ARG(ldp <= ldp_cap, "bn_bwd_reduce_t: partial buffer too small");
     dim3 grid(cdiv(C, 64), nchunk), block(256);
     const float* nf = nullptr;
-    if (relu && gout) hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, true, false, true>), grid, block, 0, st, R, C, rpc, dy, y, z, mean, invstd, nf, nf, partial, gout, ldp);
-    else if (relu)    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, true, false, false>), grid, block, 0, st, R, C, rpc, dy, y, z, mean, invstd, nf, nf, partial, (float*)nullptr, ldp);
-    else              hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, false, false, false>), grid, block, 0, st, R, C, rpc, dy, y, z, mean, invstd, nf, nf, partial, (float*)nullptr, ldp);
+#define SCN_BR(T_, RELU_, GOUT_) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T_, RELU_, false, GOUT_>), grid, block, 0, st, R, C, rpc, (const T_*)dy, (const T_*)y, (const T_*)z, mean, invstd, nf, nf, partial, (T_*)gout, ldp)
+    if (bf16) { if (relu && gout) SCN_BR(__bf16, true, true); else if (relu) SCN_BR(__bf16, true, false); else SCN_BR(__bf16, false, false); }
+    else      { if (relu && gout) SCN_BR(float, true, true); else if (relu) SCN_BR(float, true, false); else SCN_BR(float, false, false); }
+#undef SCN_BR
     SCN_LAUNCH_CHECK();
     if (nchunk_out) *nchunk_out = nchunk;
     return 0;
 }
 
-int bn_bwd_dx_fin(hipStream_t st, long R, int C, const float* g, const float* z, const float* mean, const float* invstd,
-                  const float* gamma, const float* partial, int ldp, int nchunk, float* dbeta, float* dgamma, float* dz) {
+int bn_bwd_dx_fin(hipStream_t st, long R, int C, const void* g, const void* z, int bf16, const float* mean, const float* invstd,
+                  const float* gamma, const float* partial, int ldp, int nchunk, float* dbeta, float* dgamma, void* dz) {
     SCN_ARG(R > 0 && C > 0 && C % 4 == 0 && g && z && mean && invstd && gamma && partial && ldp >= nchunk && ldp % 4 == 0 &&
-            nchunk > 0 && dbeta && dgamma && dz && aligned16(g) && aligned16(z) && aligned16(dz) && aligned16(partial), "bn_bwd_dx_fin: bad argument");
+            nchunk > 0 && dbeta && dgamma && dz && aligned16(partial), "bn_bwd_dx_fin: bad argument");
+    SCN_ARG(((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(dz)) & (bf16 ? 7u : 15u)) == 0,
+            "bn_bwd_dx_fin: maps are not vector aligned");
     SCN_ARG(2L * C * ldp * 4 < 0x7fffffffL, "bn_bwd_dx_fin: partial too large");
     int rpc;
     const int nch = ew_chunks(R, C, &rpc);
-    hipLaunchKernelGGL(bn_bwd_dx_fin_kernel, dim3(cdiv(C, 64), nch), dim3(256), 0, st, R, C, rpc, g, z, mean, invstd, gamma, partial,
-                       ldp, nchunk, dbeta, dgamma, dz);
+    if (bf16) hipLaunchKernelGGL(bn_bwd_dx_fin_kernel<__bf16>, dim3(cdiv(C, 64), nch), dim3(256), 0, st, R, C, rpc, (const __bf16*)g, (const __bf16*)z,
+                                 mean, invstd, gamma, partial, ldp, nchunk, dbeta, dgamma, (__bf16*)dz);
+    else      hipLaunchKernelGGL(bn_bwd_dx_fin_kernel<float>, dim3(cdiv(C, 64), nch), dim3(256), 0, st, R, C, rpc, (const float*)g, (const float*)z,
+                                 mean, invstd, gamma, partial, ldp, nchunk, dbeta, dgamma, (float*)dz);
     SCN_LAUNCH_CHECK();
     return 0;
 }

@@ -53,7 +53,7 @@ int conv3x3_wgrad_halo(hipStream_t st, int N, int H, int W, int C, int Co, const
 int stem_tiles(int N, int H, int W);
 int stem_conv7(hipStream_t st, int N, int H, int W, const float* x, long sn, long sc, long sh, long sw, const float* w,
                long wn, long wc, long wh, long ww, float* z, float* partial, const float* stat_shift);
-int stem_bn_relu_maxpool(hipStream_t st, int N, int Hz, int Wz, int C, const float* z, const float* ss, float* out);
+int stem_bn_relu_maxpool(hipStream_t st, int N, int Hz, int Wz, int C, const float* z, const float* ss, void* out, int out_bf16);
 
 // ---- skinny.hip ------------------------------------------------------------------------------
 int skinny_pick_ksplit(int rows, int N, int K, int groups);
@@ -174,12 +174,26 @@ int bn_bwd(hipStream_t st, int R, int C, const void* dy, const void* y, const vo
 int bn_finalize_t(hipStream_t st, long R, int C, const float* partial, int ldp, int nchunk, const float* shift, float eps,
                   float momentum, float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma,
                   const float* beta, float* ss_out);
-int bn_apply_fin(hipStream_t st, long R, int C, const float* z, const float* res, const float* partial, int ldp, int nchunk,
-                 const float* shift, float eps, float momentum, const float* gamma, const float* beta, int relu, float* y,
+// bf16 != 0: the maps (z, res, y / dy, y, z, gout / g, z, dz) hold bf16; statistics, partials and parameters stay fp32
+int bn_apply_fin(hipStream_t st, long R, int C, const void* z, const void* res, int bf16, const float* partial, int ldp, int nchunk,
+                 const float* shift, float eps, float momentum, const float* gamma, const float* beta, int relu, void* y,
                  float* mean, float* invstd, float* run_mean, float* run_var, float* ss_out);
-int bn_bwd_reduce_t(hipStream_t st, int R, int C, const float* dy, const float* y, const float* z, const float* mean,
-                    const float* invstd, int relu, float* partial, int ldp_cap, float* gout, int* nchunk_out);
-int bn_bwd_dx_fin(hipStream_t st, long R, int C, const float* g, const float* z, const float* mean, const float* invstd,
-                  const float* gamma, const float* partial, int ldp, int nchunk, float* dbeta, float* dgamma, float* dz);
+int bn_bwd_reduce_t(hipStream_t st, int R, int C, const void* dy, const void* y, const void* z, int bf16, const float* mean,
+                    const float* invstd, int relu, float* partial, int ldp_cap, void* gout, int* nchunk_out);
+int bn_bwd_dx_fin(hipStream_t st, long R, int C, const void* g, const void* z, int bf16, const float* mean, const float* invstd,
+                  const float* gamma, const float* partial, int ldp, int nchunk, float* dbeta, float* dgamma, void* dz);
+
+// ---- bf16 convolution path (BASELINE configs[4]): cgemm16.hip, wgrad16.hip, misc.hip ----------------------------------------
+int cgemm16(hipStream_t st, int M, int N, int K, const void* A, long lda, const void* B, long ldb, float beta, void* C, long ldc,
+            int out_bf16, float* ws, long ws_floats, const ConvExtra* ex, int flip);
+int wgrad16_3x3(hipStream_t st, int N, int H, int W, int C, int Co, const void* dy, const void* x, float* dw, float* ws,
+                long ws_floats, int force_split);
+int wgrad16_rows(hipStream_t st, int R, int C, int Co, const void* dy, const void* x, long src_rows, float* dw, long ldo,
+                 int gs, int gHi, int gWi, int gHo, int gWo, int goh, int gow, float* ws, long ws_floats, int force_split);
+// One launch converts every convolution weight of a trunk: fp32 master [Cout][taps][Cin] -> bf16 copy in the same layout
+// and a TRANSPOSED bf16 copy [Cin][taps][Cout] (the B operand of the d-input products).  desc: device array of
+// WeightDesc, tile_prefix[n+1]: exclusive prefix sums of each weight's 32 x 32 tile count (taps * Cout/32 * Cin/32).
+struct WeightDesc { const float* src; void* dst; void* dst_t; int cout, taps, cin, pad; };
+int bf16_weights(hipStream_t st, int n, const WeightDesc* desc, const int* tile_prefix, int total_tiles);
 
 }  // namespace scn

@@ -432,4 +432,51 @@ int clamp_adam(hipStream_t st, long n, float* p, const float* g, float* m, float
     return 0;
 }
 
+// ---- fp32 master weights -> bf16 operand copies of the mixed-precision trunk (one launch per step) ---------------------------
+namespace {
+__global__ __launch_bounds__(256) void bf16_weights_kernel(int n, const WeightDesc* __restrict__ desc, const int* __restrict__ prefix) {
+    __shared__ float tile[32][33];
+    // which weight owns this 32 x 32 tile: binary search over the exclusive prefix sums (wave-uniform)
+    int lo = 0, hi = n - 1;
+    const int t = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (prefix[mid] <= t) lo = mid; else hi = mid - 1;
+    }
+    const WeightDesc d = desc[lo];
+    int r = t - prefix[lo];
+    const int tci = d.cin >> 5, tco = d.cout >> 5;
+    const int tap = r / (tco * tci);
+    r -= tap * tco * tci;
+    const int co0 = (r / tci) << 5, ci0 = (r % tci) << 5;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8 threads, 4 rows each
+    const long ld = (long)d.taps * d.cin, ldt = (long)d.taps * d.cout;
+    unsigned short* dst = reinterpret_cast<unsigned short*>(d.dst);
+    unsigned short* dstt = reinterpret_cast<unsigned short*>(d.dst_t);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int co = co0 + ty + 8 * k;
+        const float v = d.src[(long)co * ld + (long)tap * d.cin + ci0 + tx];
+        tile[ty + 8 * k][tx] = v;
+        if (dst) dst[(long)co * ld + (long)tap * d.cin + ci0 + tx] = __builtin_bit_cast(unsigned short, (__bf16)v);
+    }
+    __syncthreads();
+    if (dstt) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ci = ci0 + ty + 8 * k;
+            dstt[(long)ci * ldt + (long)tap * d.cout + co0 + tx] = __builtin_bit_cast(unsigned short, (__bf16)tile[tx][ty + 8 * k]);
+        }
+    }
+}
+}  // namespace
+
+int bf16_weights(hipStream_t st, int n, const WeightDesc* desc, const int* tile_prefix, int total_tiles) {
+    if (n <= 0 || total_tiles <= 0) return 0;
+    SCN_ARG(desc && tile_prefix, "bf16_weights: null table");
+    hipLaunchKernelGGL(bf16_weights_kernel, dim3(total_tiles), dim3(256), 0, st, n, desc, tile_prefix);
+    SCN_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace scn

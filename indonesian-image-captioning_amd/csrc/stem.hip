@@ -145,9 +145,10 @@ __global__ __launch_bounds__(256, 3) void stem_conv7_kernel(StemArgs g) {
 }
 
 // out[(n,oh,ow)][c] = max over the 3x3 / stride 2 / padding 1 window of relu(z*scale[c] + shift[c]); 4 channels per thread
+template <bool OBF>
 __global__ __launch_bounds__(256) void stem_bn_relu_maxpool_kernel(long total4, int C, int Hz, int Wz, int Ho, int Wo,
                                                                    const float* __restrict__ z, const float* __restrict__ ss,
-                                                                   float* __restrict__ out) {
+                                                                   void* __restrict__ out) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total4) return;
     const int c4n = C >> 2;
@@ -177,7 +178,12 @@ __global__ __launch_bounds__(256) void stem_bn_relu_maxpool_kernel(long total4, 
 #pragma unroll
             for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], fmaf(v[q][e], sc[e], sh[e]));
         }
-    *reinterpret_cast<f32x4*>(out + pix * C + c) = m;
+    if (OBF) {        // bf16 map for the mixed-precision trunk
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(out) + pix * C + c) = bf16x4{(__bf16)m[0], (__bf16)m[1], (__bf16)m[2], (__bf16)m[3]};
+    } else {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + pix * C + c) = m;
+    }
 }
 
 }  // namespace
@@ -210,11 +216,12 @@ int stem_conv7(hipStream_t st, int N, int H, int W, const float* x, long sn, lon
 }
 
 // z [N*Hz*Wz][C] -> out [N*Ho*Wo][C], Ho = (Hz-1)/2+1; ss [C][2] = {scale, shift}
-int stem_bn_relu_maxpool(hipStream_t st, int N, int Hz, int Wz, int C, const float* z, const float* ss, float* out) {
+int stem_bn_relu_maxpool(hipStream_t st, int N, int Hz, int Wz, int C, const float* z, const float* ss, void* out, int out_bf16) {
     SCN_ARG(N > 0 && Hz > 0 && Wz > 0 && C % 4 == 0 && aligned16(z) && aligned16(ss) && aligned16(out), "stem_bn_relu_maxpool: arguments");
     const int Ho = (Hz - 1) / 2 + 1, Wo = (Wz - 1) / 2 + 1;
     const long total4 = (long)N * Ho * Wo * (C / 4);
-    hipLaunchKernelGGL(stem_bn_relu_maxpool_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, st, total4, C, Hz, Wz, Ho, Wo, z, ss, out);
+    if (out_bf16) hipLaunchKernelGGL(stem_bn_relu_maxpool_kernel<true>, dim3(cdiv(total4, 256)), dim3(256), 0, st, total4, C, Hz, Wz, Ho, Wo, z, ss, out);
+    else          hipLaunchKernelGGL(stem_bn_relu_maxpool_kernel<false>, dim3(cdiv(total4, 256)), dim3(256), 0, st, total4, C, Hz, Wz, Ho, Wo, z, ss, out);
     SCN_LAUNCH_CHECK();
     return 0;
 }

@@ -41,7 +41,9 @@ class EncoderCaption(nn.Module):
                 self._bn_counters = flat = manage_bn_counters(self.resnet)
             if flat is not None:
                 flat.add_(1)     # all BatchNorm num_batches_tracked counters, one launch
-        out = run_trunk(self.resnet, images)      # stem on csrc/stem.hip, Bottlenecks on scnattn/conv.py
+        out = run_trunk(self.resnet, images)      # stem on csrc/stem.hip, Bottlenecks on scnattn/conv.py (conv16.py in bf16)
+        if out.dtype == torch.bfloat16:           # mixed-precision trunk: the decoder takes (and returns gradients for) fp32
+            out = out.float()
         pre = out.permute(0, 2, 3, 1)             # a contiguous (B, h, w, C) view when the trunk is channels-last
         if not pooled:
             return pre

@@ -35,7 +35,8 @@ class EncoderTagger(nn.Module):
                 self._bn_counters = flat = manage_bn_counters(self.resnet)
             if flat is not None:
                 flat.add_(1)
-        out = run_trunk(self.resnet, images)      # stem on csrc/stem.hip, Bottlenecks on scnattn/conv.py
+        out = run_trunk(self.resnet, images)      # stem on csrc/stem.hip, Bottlenecks on scnattn/conv.py (conv16.py in bf16)
+        out = out.float()
         out = out.reshape(out.size(0), -1)
         out = self.dropout(out)
         out = SF.linear(out, self.linear.weight, self.linear.bias)

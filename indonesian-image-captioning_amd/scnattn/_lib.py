@@ -79,12 +79,18 @@ _SIGS = {
     "scnattn_conv3x3_dgrad_strided": ([vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i64], i32),
     "scnattn_cgemm_stat_ld": ([i32], i32),
     "scnattn_bn_finalize": ([vp, i64, i32, vp, i32, i32, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp], i32),
-    "scnattn_bn_apply_fin": ([vp, i64, i32, vp, vp, vp, i32, i32, vp, f32, f32, vp, vp, i32, vp, vp, vp, vp, vp, vp], i32),
-    "scnattn_bn_bwd_reduce": ([vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, C.POINTER(C.c_int)], i32),
-    "scnattn_bn_bwd_dx_fin": ([vp, i64, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp], i32),
+    "scnattn_bn_apply_fin": ([vp, i64, i32, vp, vp, i32, vp, i32, i32, vp, f32, f32, vp, vp, i32, vp, vp, vp, vp, vp, vp], i32),
+    "scnattn_bn_bwd_reduce": ([vp, i32, i32, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp, C.POINTER(C.c_int)], i32),
+    "scnattn_bn_bwd_dx_fin": ([vp, i64, i32, vp, vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp], i32),
+    "scnattn_bf16_weights": ([vp, i32, vp, vp, i32], i32),
+    "scnattn_cgemm16": ([vp, i32, i32, i32, vp, i64, vp, i64, f32, vp, i64, i32, vp, i64, C.POINTER(ConvExtra)], i32),
+    "scnattn_conv3x3_fwd16": ([vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, C.POINTER(ConvExtra), vp, i64], i32),
+    "scnattn_conv3x3_dgrad16": ([vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i64], i32),
+    "scnattn_wgrad16_3x3": ([vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i64, i32], i32),
+    "scnattn_wgrad16_rows": ([vp, i32, i32, i32, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp, i64, i32], i32),
     "scnattn_stem_tiles": ([i32, i32, i32], i32),
     "scnattn_stem_conv7": ([vp, i32, i32, i32, vp, i64, i64, i64, i64, vp, i64, i64, i64, i64, vp, vp, vp], i32),
-    "scnattn_stem_bn_relu_maxpool": ([vp, i32, i32, i32, i32, vp, vp, vp], i32),
+    "scnattn_stem_bn_relu_maxpool": ([vp, i32, i32, i32, i32, vp, vp, vp, i32], i32),
     "scnattn_bn_stats_fold": ([vp, i32, i32, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp], i32),
     "scnattn_skinny_gemm": ([vp, i32, i32, i32, i32, vp, i64, i64, vp, i64, i64, vp, i64, i64, i64, i32,
                              C.POINTER(i32)], i32),

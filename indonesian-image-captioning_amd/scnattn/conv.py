@@ -245,7 +245,8 @@ def _apply_fin(h, st, R, Cn, z, res, part, bn_mod, shift, gamma, beta, relu):
     """y = [relu](bn(z) [+ res]) with the statistics finalized inside the same launch (csrc/batchnorm.hip)."""
     stats = torch.empty((2, Cn), device=z.device, dtype=torch.float32)
     y = torch.empty_like(z)
-    _chk(h.scnattn_bn_apply_fin(st, R, Cn, z.data_ptr(), None if res is None else res.data_ptr(), part.data_ptr(),
+    _chk(h.scnattn_bn_apply_fin(st, R, Cn, z.data_ptr(), None if res is None else res.data_ptr(),
+                                1 if z.dtype == torch.bfloat16 else 0, part.data_ptr(),
                                 h.scnattn_cgemm_stat_ld(R), h.scnattn_cgemm_row_tiles(R), shift.data_ptr(), bn_mod.eps,
                                 bn_mod.momentum, gamma.data_ptr(), beta.data_ptr(), 1 if relu else 0, y.data_ptr(),
                                 stats[0].data_ptr(), stats[1].data_ptr(), bn_mod.running_mean.data_ptr(),
@@ -256,10 +257,10 @@ def _apply_fin(h, st, R, Cn, z, res, part, bn_mod, shift, gamma, beta, relu):
 
 def _bwd_reduce(h, st, R, Cn, dy, y, z, stats, relu, bnpart, want_g):
     """BatchNorm(+ReLU) backward, first half: g = dy * [y > 0] (or dy) and the channel-major partial sums of g, g*xhat."""
-    g = torch.empty((R, Cn), device=dy.device, dtype=torch.float32) if want_g else None
+    g = torch.empty((R, Cn), device=dy.device, dtype=dy.dtype) if want_g else None
     nch = C.c_int(0)
     _chk(h.scnattn_bn_bwd_reduce(st, R, Cn, dy.data_ptr(), None if y is None else y.data_ptr(), z.data_ptr(),
-                                 stats[0].data_ptr(), stats[1].data_ptr(), 1 if relu else 0, bnpart.data_ptr(),
+                                 1 if dy.dtype == torch.bfloat16 else 0, stats[0].data_ptr(), stats[1].data_ptr(), 1 if relu else 0, bnpart.data_ptr(),
                                  bnpart.numel() // (2 * Cn), None if g is None else g.data_ptr(), C.byref(nch)),
          "scnattn_bn_bwd_reduce")
     return g, nch.value
@@ -268,7 +269,8 @@ def _bwd_reduce(h, st, R, Cn, dy, y, z, stats, relu, bnpart, want_g):
 def _bwd_dx_fin(h, st, R, Cn, g, z, stats, gamma, partial, ldp, nchunk, dz):
     """Second half: d beta / d gamma summed from the partials and dz, one launch; dz may alias g."""
     dgb = torch.empty((2, Cn), device=g.device, dtype=torch.float32)
-    _chk(h.scnattn_bn_bwd_dx_fin(st, R, Cn, g.data_ptr(), z.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
+    _chk(h.scnattn_bn_bwd_dx_fin(st, R, Cn, g.data_ptr(), z.data_ptr(), 1 if g.dtype == torch.bfloat16 else 0,
+                                 stats[0].data_ptr(), stats[1].data_ptr(),
                                  gamma.data_ptr(), partial.data_ptr(), ldp, nchunk, dgb[0].data_ptr(), dgb[1].data_ptr(),
                                  dz.data_ptr()), "scnattn_bn_bwd_dx_fin")
     return dgb

@@ -67,6 +67,10 @@ class Bottleneck(nn.Module):
         from . import conv as _conv
         if _conv.usable(self, x):
             return _conv.bottleneck(self, x)
+        if x.dtype == torch.bfloat16:        # the mixed-precision trunk (bf16 maps from scnattn/stem.py under bf16 autocast)
+            from . import conv16 as _c16
+            if _c16.usable(self, x):
+                return _c16.bottleneck(self, x)
         identity = x if self.downsample is None else self.downsample(x)
         out = self.bn1(self.conv1(x), relu=True)
         out = self.bn2(self.conv2(out), relu=True)

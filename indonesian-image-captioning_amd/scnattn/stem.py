@@ -14,7 +14,9 @@ from . import conv as _conv
 
 
 def usable(trunk, x):
-    if not (_conv.ENABLED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and not torch.is_autocast_enabled()):
+    if not (_conv.ENABLED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+        return False
+    if torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") != torch.bfloat16:
         return False
     if len(trunk) < 4:
         return False
@@ -37,8 +39,10 @@ def usable(trunk, x):
     return True
 
 
-def stem(trunk, x):
-    """(N,3,H,W) -> (N,64,Hp,Wp) channels-last, Hp = ((H-1)//2) // 2 + 1 (= H/4 for the 256 x 256 inputs)."""
+def stem(trunk, x, bf16=False):
+    """(N,3,H,W) -> (N,64,Hp,Wp) channels-last, Hp = ((H-1)//2) // 2 + 1 (= H/4 for the 256 x 256 inputs).  bf16: the
+    pooled map is written as bf16 (the mixed-precision trunk); the convolution itself stays fp32 (K = 147: 1 % of the
+    trunk's work)."""
     c1, bn = trunk[0], trunk[1]
     h = _lib.lib()
     dev = x.device
@@ -70,8 +74,8 @@ def stem(trunk, x):
         with torch.no_grad():       # 64 channels: the folded {scale, shift} of the running statistics
             sc = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
             ss.copy_(torch.stack([sc, bn.bias - bn.running_mean * sc], dim=1))
-    out = torch.empty((N * Hp * Wp, 64), device=dev, dtype=torch.float32)
-    _conv._chk(h.scnattn_stem_bn_relu_maxpool(st, N, Hz, Wz, 64, z.data_ptr(), ss.data_ptr(), out.data_ptr()),
+    out = torch.empty((N * Hp * Wp, 64), device=dev, dtype=torch.bfloat16 if bf16 else torch.float32)
+    _conv._chk(h.scnattn_stem_bn_relu_maxpool(st, N, Hz, Wz, 64, z.data_ptr(), ss.data_ptr(), out.data_ptr(), 1 if bf16 else 0),
                "scnattn_stem_bn_relu_maxpool")
     return out.view(N, Hp, Wp, 64).permute(0, 3, 1, 2)
 
@@ -79,7 +83,11 @@ def stem(trunk, x):
 def run_trunk(trunk, x):
     """`trunk(x)` with the four stem children on the fused kernels when they qualify."""
     if usable(trunk, x):
-        y = stem(trunk, x)
+        bf16 = torch.is_autocast_enabled()          # bf16 autocast = the mixed-precision trunk (scnattn/conv16.py)
+        if bf16:
+            from . import conv16 as _c16
+            _c16.refresh_weights(trunk)              # fp32 master weights -> bf16 operand copies, one launch
+        y = stem(trunk, x, bf16)
         for child in list(trunk.children())[4:]:
             y = child(y)
         return y

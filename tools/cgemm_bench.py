@@ -272,7 +272,7 @@ def checkbn():
             for use_res in (False, True):
                 y = torch.full((R, Cn), float("nan"), device=dev); st = torch.empty(2, Cn, device=dev)
                 rm = torch.zeros(Cn, device=dev); rv = torch.ones(Cn, device=dev); ss = torch.empty(Cn, 2, device=dev)
-                call("scnattn_bn_apply_fin", stream_of(z), R, Cn, ptr(z), ptr(res) if use_res else None, ptr(part), ld, mt, ptr(shift),
+                call("scnattn_bn_apply_fin", stream_of(z), R, Cn, ptr(z), ptr(res) if use_res else None, 0, ptr(part), ld, mt, ptr(shift),
                      eps, mom, ptr(ga), ptr(be), relu, ptr(y), ptr(st[0]), ptr(st[1]), ptr(rm), ptr(rv), ptr(ss))
                 ref = (zd - mu) / torch.sqrt(var + eps) * ga.double() + be.double()
                 if use_res: ref = ref + res.double()
@@ -292,7 +292,7 @@ def checkbn():
         bpart = torch.full((2, Cn, cap), float("nan"), device=dev)
         gout = torch.full((R, Cn), float("nan"), device=dev)
         nch = C.c_int(0)
-        call("scnattn_bn_bwd_reduce", stream_of(z), R, Cn, ptr(dy), ptr(yv), ptr(z), ptr(st[0]), ptr(st[1]), 1, ptr(bpart), cap, ptr(gout), C.byref(nch))
+        call("scnattn_bn_bwd_reduce", stream_of(z), R, Cn, ptr(dy), ptr(yv), ptr(z), 0, ptr(st[0]), ptr(st[1]), 1, ptr(bpart), cap, ptr(gout), C.byref(nch))
         gref = dy.double() * (yv > 0).double()
         assert torch.equal(gout.double(), gref)
         xh = (zd - st[0].double()) * st[1].double()
@@ -301,12 +301,164 @@ def checkbn():
         e1 = rel(bp[0, :, :nch.value].double().sum(1), gref.sum(0)); e2 = rel(bp[1, :, :nch.value].double().sum(1), (gref * xh).sum(0))
         assert e1 < 2e-5 and e2 < 2e-5, ("bn_bwd_reduce", R, Cn, e1, e2)
         dz = torch.full((R, Cn), float("nan"), device=dev); dgb = torch.empty(2, Cn, device=dev)
-        call("scnattn_bn_bwd_dx_fin", stream_of(z), R, Cn, ptr(gout), ptr(z), ptr(st[0]), ptr(st[1]), ptr(ga), ptr(bp), ldb, nch.value, ptr(dgb[0]), ptr(dgb[1]), ptr(dz))
+        call("scnattn_bn_bwd_dx_fin", stream_of(z), R, Cn, ptr(gout), ptr(z), 0, ptr(st[0]), ptr(st[1]), ptr(ga), ptr(bp), ldb, nch.value, ptr(dgb[0]), ptr(dgb[1]), ptr(dz))
         db, dg = gref.sum(0), (gref * xh).sum(0)
         dzr = ga.double() * st[1].double() * (gref - db / R - xh * dg / R)
         assert rel(dgb[0], db) < 2e-5 and rel(dgb[1], dg) < 2e-5
         e = rel(dz, dzr); assert e < 2e-5, ("bn_bwd_dx_fin", R, Cn, e)
     print("checkbn ok", flush=True)
+
+
+def check16():
+    """bf16 convolution path (csrc/cgemm16.hip, csrc/wgrad16.hip, scnattn_bf16_weights) against fp64 on the bf16-rounded
+    operands: fp32 outputs (weight gradients, fp32-output products) 2e-5 -- only the fp32 accumulation order differs --,
+    bf16 outputs 4e-3 of the largest element (one rounding to 8 significant bits), statistics 2e-5."""
+    from scnattn import conv16 as C16
+    BF = torch.bfloat16
+    g = torch.Generator(device="cpu").manual_seed(5)
+    rnd = lambda *sh, sc=1.0: (sc * torch.randn(*sh, generator=g)).to(dev).to(BF)
+    # ---- plain products: forward / d input of 1x1 convolutions, both row tiles, split-K, statistics, beta, gather -------
+    for (R, Cin, Cout) in [(2048, 512, 2048), (8192, 1024, 256), (300, 64, 72), (4096, 256, 64), (640, 2048, 512)]:
+        x = rnd(R, Cin); w = rnd(Cout, Cin, sc=0.1); c0 = rnd(R, Cout)
+        ref = x.double() @ w.double().t()
+        for split, mi, obf in ((0, 0, 1), (1, 1, 1), (1, 2, 0), (2, 0, 1), (4, 2, 0)):
+            if split > 1 and Cin // split < 32:
+                continue
+            mt = lib().scnattn_cgemm_row_tiles(R); ld = lib().scnattn_cgemm_stat_ld(R)
+            part = torch.full((2, Cout, ld), float("nan"), device=dev)
+            sft = (0.1 * torch.randn(Cout, generator=g)).to(dev)
+            ex = ConvExtra(epi=1, stat_partial=part.data_ptr(), stat_shift=sft.data_ptr(), force_split=split, force_mi=mi)
+            y = torch.full((R, Cout), float("nan"), device=dev, dtype=BF if obf else torch.float32)
+            call("scnattn_cgemm16", stream_of(x), R, Cout, Cin, ptr(x), Cin, ptr(w), Cin, 0.0, ptr(y), Cout, obf, ptr(WS), WS.numel(), C.byref(ex))
+            e = rel(y, ref); assert e < (4e-3 if obf else 2e-5), ("cgemm16", R, Cin, Cout, split, mi, obf, e)
+            d = ref - sft.double()
+            e1 = rel(part[0, :, :mt].double().sum(1), d.sum(0)); e2 = rel(part[1, :, :mt].double().sum(1), (d * d).sum(0))
+            assert e1 < 2e-5 and e2 < 2e-5, ("cgemm16 stats", R, Cin, Cout, split, e1, e2)
+            # beta = 1 accumulate (conv1's d input into the residual gradient)
+            yb = c0.clone() if obf else c0.float().clone()
+            call("scnattn_cgemm16", stream_of(x), R, Cout, Cin, ptr(x), Cin, ptr(w), Cin, 1.0, ptr(yb), Cout, obf, ptr(WS), WS.numel(),
+                 C.byref(ConvExtra(force_split=split, force_mi=mi)))
+            e = rel(yb, ref + c0.double()); assert e < (4e-3 if obf else 2e-5), ("cgemm16 beta", R, Cin, Cout, split, mi, obf, e)
+    Bn, Hi, Cin, Cout = 3, 8, 64, 128
+    xm = rnd(Bn, Hi, Hi, Cin); w = rnd(Cout, Cin, sc=0.1)
+    xs = xm[:, ::2, ::2].reshape(-1, Cin).contiguous()
+    y = torch.empty(xs.shape[0], Cout, device=dev, dtype=BF)
+    ex = ConvExtra(stride=2, Hi=Hi, Wi=Hi, Ho=Hi // 2, Wo=Hi // 2)
+    call("scnattn_cgemm16", stream_of(xm), xs.shape[0], Cout, Cin, ptr(xm), Cin, ptr(w), Cin, 0.0, ptr(y), Cout, 1, ptr(WS), WS.numel(), C.byref(ex))
+    e = rel(y, xs.double() @ w.double().t()); assert e < 4e-3, ("cgemm16 gather", e)
+    # ---- 3x3: forward, d input (stride 1 = forward with flipped taps on the transposed copy; stride 2 = parity classes),
+    #      weight gradients (halo-staged stride 1; stride 2 tap by tap), and the weight conversion kernel ------------------
+    for (N, H, W, Cin, Cout, s) in [(2, 8, 8, 128, 128, 1), (3, 10, 12, 64, 256, 2), (2, 7, 16, 256, 64, 1), (2, 16, 16, 128, 128, 2),
+                                    (1, 5, 40, 512, 512, 1), (32, 16, 16, 256, 256, 1), (4, 32, 32, 128, 128, 2), (2, 3, 4, 64, 64, 1)]:
+        conv = torch.nn.Conv2d(Cin, Cout, 3, stride=s, padding=1, bias=False).to(dev).to(memory_format=torch.channels_last)
+        trunk = torch.nn.Sequential(conv)
+        C16.refresh_weights(trunk)
+        wq = conv.weight.detach().to(BF)
+        assert torch.equal(conv._w16.view(Cout, 3, 3, Cin), wq.permute(0, 2, 3, 1)), "bf16 weight copy"
+        assert torch.equal(conv._w16t.view(Cin, 3, 3, Cout), wq.permute(1, 2, 3, 0)), "transposed bf16 weight copy"
+        x = rnd(N, H, W, Cin)
+        Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+        xd = x.double().permute(0, 3, 1, 2).requires_grad_(True); wd_ = wq.double().requires_grad_(True)
+        ref = F.conv2d(xd, wd_, stride=s, padding=1)
+        y = torch.full((N * Ho * Wo, Cout), float("nan"), device=dev, dtype=BF)
+        mt = lib().scnattn_cgemm_row_tiles(N * Ho * Wo); ld = lib().scnattn_cgemm_stat_ld(N * Ho * Wo)
+        part = torch.full((2, Cout, ld), float("nan"), device=dev)
+        ex = ConvExtra(epi=1, stat_partial=part.data_ptr())
+        call("scnattn_conv3x3_fwd16", stream_of(x), N, H, W, Cin, Cout, s, ptr(x), ptr(conv._w16), ptr(y), C.byref(ex), ptr(WS), WS.numel())
+        r2 = ref.detach().permute(0, 2, 3, 1).reshape(-1, Cout)
+        e = rel(y, r2); assert e < 4e-3, ("conv3 fwd16", N, H, W, Cin, Cout, s, e)
+        e1 = rel(part[0, :, :mt].double().sum(1), r2.sum(0)); assert e1 < 2e-5 or r2.sum(0).abs().max() < 1e-3, ("conv3 fwd16 stats", e1)
+        dy = rnd(N, Ho, Wo, Cout)
+        ref.backward(dy.double().permute(0, 3, 1, 2))
+        if s == 1 or (H % 2 == 0 and W % 2 == 0):
+            dx = torch.full((N * H * W, Cin), float("nan"), device=dev, dtype=BF)
+            call("scnattn_conv3x3_dgrad16", stream_of(x), N, H, W, Cin, Cout, s, ptr(dy), ptr(conv._w16t), ptr(dx), ptr(WS), WS.numel())
+            e = rel(dx, xd.grad.permute(0, 2, 3, 1).reshape(-1, Cin)); assert e < 4e-3, ("conv3 dgrad16", N, H, W, Cin, Cout, s, e)
+        dwr = wd_.grad.permute(0, 2, 3, 1)                 # [Cout][3][3][Cin]
+        dw = torch.full((Cout, 3, 3, Cin), float("nan"), device=dev)
+        if s == 1:
+            for ksl in (0, 1, 3):
+                if ksl > max(1, (N * ((W + 15) // 16) * H) // 16) or ksl * dw.numel() > WS.numel():
+                    continue
+                dw.fill_(float("nan"))
+                call("scnattn_wgrad16_3x3", stream_of(x), N, H, W, Cin, Cout, ptr(dy), ptr(x), ptr(dw), ptr(WS), WS.numel(), ksl)
+                e = rel(dw, dwr); assert e < 2e-5, ("wgrad16 3x3", N, H, W, Cin, Cout, ksl, e)
+        elif Cin % 64 == 0 and Cout % 64 == 0:
+            for tap in range(9):
+                call("scnattn_wgrad16_rows", stream_of(x), N * Ho * Wo, Cin, Cout, ptr(dy), ptr(x), N * H * W, dw.data_ptr() + 4 * tap * Cin, 9 * Cin,
+                     s, H, W, Ho, Wo, tap // 3 - 1, tap % 3 - 1, ptr(WS), WS.numel(), 0)
+            e = rel(dw, dwr); assert e < 2e-5, ("wgrad16 strided 3x3 by taps", N, H, W, Cin, Cout, e)
+    # ---- 1x1 weight gradients: plain, forced splits, strided downsample ------------------------------------------------------
+    for (R, Cin, Cout) in [(2048, 512, 2048), (8192, 1024, 256), (300, 64, 128), (131072, 64, 64), (37, 128, 64)]:
+        x = rnd(R, Cin); dy = rnd(R, Cout)
+        ref = dy.double().t() @ x.double()
+        for ksl in (0, 1, 2, 5):
+            if ksl > max(1, ((R + 15) // 16) // 16):
+                continue
+            dw = torch.full((Cout, Cin), float("nan"), device=dev)
+            call("scnattn_wgrad16_rows", stream_of(x), R, Cin, Cout, ptr(dy), ptr(x), R, ptr(dw), Cin, 0, 0, 0, 0, 0, 0, 0, ptr(WS), WS.numel(), ksl)
+            e = rel(dw, ref); assert e < 2e-5, ("wgrad16 rows", R, Cin, Cout, ksl, e)
+    xm = rnd(3, 8, 12, 64); dy = rnd(3 * 4 * 6, 128)
+    dw = torch.full((128, 64), float("nan"), device=dev)
+    call("scnattn_wgrad16_rows", stream_of(xm), 72, 64, 128, ptr(dy), ptr(xm), 3 * 8 * 12, ptr(dw), 64, 2, 8, 12, 4, 6, 0, 0, ptr(WS), WS.numel(), 0)
+    e = rel(dw, dy.double().t() @ xm[:, ::2, ::2].reshape(-1, 64).double()); assert e < 2e-5, ("wgrad16 strided 1x1", e)
+    # ---- BatchNorm finalize-on-load kernels on bf16 maps -----------------------------------------------------------------------
+    for (R, Cn) in [(2048, 512), (300, 64), (8192, 256)]:
+        z = rnd(R, Cn); res = rnd(R, Cn)
+        ga = (1 + 0.3 * torch.randn(Cn, generator=g)).to(dev); be = (0.2 * torch.randn(Cn, generator=g)).to(dev)
+        zd = z.double(); shift = zd.mean(0).float().contiguous()
+        mt = lib().scnattn_cgemm_row_tiles(R); ld = lib().scnattn_cgemm_stat_ld(R)
+        part = torch.zeros((2, Cn, ld), device=dev)
+        d = zd - shift.double()
+        part[0, :, 0] = d.sum(0).float(); part[1, :, 0] = (d * d).sum(0).float()
+        y = torch.empty(R, Cn, device=dev, dtype=BF); stt = torch.empty(2, Cn, device=dev)
+        call("scnattn_bn_apply_fin", stream_of(z), R, Cn, ptr(z), ptr(res), 1, ptr(part), ld, mt, ptr(shift), 1e-5, 0.1, ptr(ga), ptr(be), 1, ptr(y),
+             ptr(stt[0]), ptr(stt[1]), None, None, None)
+        mu, var = zd.mean(0), zd.var(0, unbiased=False)
+        ref = torch.relu((zd - mu) / torch.sqrt(var + 1e-5) * ga.double() + be.double() + res.double())
+        e = rel(y, ref); assert e < 4e-3, ("bn_apply_fin bf16", R, Cn, e)
+        dy = rnd(R, Cn); yv = torch.relu(rnd(R, Cn))
+        bpart = torch.full((2 * Cn * 260,), float("nan"), device=dev); gout = torch.empty(R, Cn, device=dev, dtype=BF); nch = C.c_int(0)
+        call("scnattn_bn_bwd_reduce", stream_of(z), R, Cn, ptr(dy), ptr(yv), ptr(z), 1, ptr(stt[0]), ptr(stt[1]), 1, ptr(bpart), 260, ptr(gout), C.byref(nch))
+        gref = dy.double() * (yv > 0).double()
+        assert torch.equal(gout.double(), gref)
+        xh = (zd - stt[0].double()) * stt[1].double()
+        ldb = (nch.value + 3) & ~3
+        dz = torch.empty(R, Cn, device=dev, dtype=BF); dgb = torch.empty(2, Cn, device=dev)
+        call("scnattn_bn_bwd_dx_fin", stream_of(z), R, Cn, ptr(gout), ptr(z), 1, ptr(stt[0]), ptr(stt[1]), ptr(ga), ptr(bpart), ldb, nch.value, ptr(dgb[0]), ptr(dgb[1]), ptr(dz))
+        db, dg = gref.sum(0), (gref * xh).sum(0)
+        assert rel(dgb[0], db) < 2e-5 and rel(dgb[1], dg) < 2e-5
+        e = rel(dz, ga.double() * stt[1].double() * (gref - db / R - xh * dg / R)); assert e < 4e-3, ("bn_bwd_dx_fin bf16", R, Cn, e)
+    print("check16 ok", flush=True)
+
+
+def time16():
+    """bf16 kernels on the trunk's shapes (B = 32): forward / d input / weight gradient per layer, us."""
+    from scnattn import conv16 as C16
+    BF = torch.bfloat16
+    print("bf16: layer | 1x1 conv1 fwd, conv3 fwd, conv1 dgrad(+beta), wgrad conv1, wgrad conv3 | 3x3 fwd, dgrad, wgrad")
+    for name, H, Cin, p, s in [("l1", 64, 256, 64, 1), ("l2", 32, 512, 128, 1), ("l3", 16, 1024, 256, 1), ("l4", 8, 2048, 512, 1),
+                               ("l3.0", 32, 512, 256, 2)]:
+        N = 32
+        Ho = H // s
+        Rin, Rout = N * H * H, N * Ho * Ho
+        x = torch.randn(Rin, Cin, device=dev).to(BF); a1 = torch.randn(Rin, p, device=dev).to(BF); a2 = torch.randn(Rout, p, device=dev).to(BF)
+        w1 = torch.randn(p, Cin, device=dev).to(BF); w1t = torch.randn(Cin, p, device=dev).to(BF); w3 = torch.randn(4 * p, p, device=dev).to(BF)
+        w2 = torch.randn(p, 9 * p, device=dev).to(BF)
+        z1 = torch.empty(Rin, p, device=dev, dtype=BF); z3 = torch.empty(Rout, 4 * p, device=dev, dtype=BF); z2 = torch.empty(Rout, p, device=dev, dtype=BF)
+        dx = torch.empty(Rin, Cin, device=dev, dtype=BF); dz1 = torch.randn(Rin, p, device=dev).to(BF); dz3 = torch.randn(Rout, 4 * p, device=dev).to(BF)
+        dz2 = torch.randn(Rout, p, device=dev).to(BF); da1 = torch.empty(Rin, p, device=dev, dtype=BF)
+        dw1 = torch.empty(p, Cin, device=dev); dw3 = torch.empty(4 * p, p, device=dev); dw2 = torch.empty(p, 9 * p, device=dev)
+        part = torch.empty(2, 4 * p, lib().scnattn_cgemm_stat_ld(Rin), device=dev)
+        ex = ConvExtra(epi=1, stat_partial=part.data_ptr())
+        mm = lambda M, Nn, K, a, b, o, beta=0.0, e=None: t_us(lambda: call("scnattn_cgemm16", stream_of(a), M, Nn, K, ptr(a), K, ptr(b), K, beta, ptr(o), Nn, 1, ptr(WS), WS.numel(), None if e is None else C.byref(e)))
+        t = [mm(Rin, p, Cin, x, w1, z1, 0.0, ex), mm(Rout, 4 * p, p, a2, w3, z3, 0.0, ex), mm(Rin, Cin, p, dz1, w1t, dx, 1.0),
+             t_us(lambda: call("scnattn_wgrad16_rows", stream_of(x), Rin, Cin, p, ptr(dz1), ptr(x), Rin, ptr(dw1), Cin, 0, 0, 0, 0, 0, 0, 0, ptr(WS), WS.numel(), 0)),
+             t_us(lambda: call("scnattn_wgrad16_rows", stream_of(x), Rout, p, 4 * p, ptr(dz3), ptr(a2), Rout, ptr(dw3), p, 0, 0, 0, 0, 0, 0, 0, ptr(WS), WS.numel(), 0)),
+             t_us(lambda: call("scnattn_conv3x3_fwd16", stream_of(x), N, H, H, p, p, s, ptr(a1), ptr(w2), ptr(z2), C.byref(ex), ptr(WS), WS.numel())),
+             t_us(lambda: call("scnattn_conv3x3_dgrad16", stream_of(x), N, H, H, p, p, s, ptr(dz2), ptr(w2), ptr(da1), ptr(WS), WS.numel())),
+             t_us(lambda: call("scnattn_wgrad16_3x3", stream_of(x), N, H, H, p, p, ptr(dz2), ptr(a1), ptr(dw2), ptr(WS), WS.numel(), 0)) if s == 1 else float("nan")]
+        print("%-5s | %s" % (name, " ".join("%7.1f" % v for v in t)), flush=True)
 
 
 def checkstem():
@@ -330,7 +482,7 @@ def checkstem():
         ss = torch.stack([1 + 0.5 * torch.randn(64, generator=g), 0.3 * torch.randn(64, generator=g)], dim=1).to(dev).contiguous()
         Hp, Wp = (Hz - 1) // 2 + 1, (Wz - 1) // 2 + 1
         out = torch.full((N * Hp * Wp, 64), float("nan"), device=dev)
-        call("scnattn_stem_bn_relu_maxpool", stream_of(x), N, Hz, Wz, 64, ptr(z), ptr(ss), ptr(out))
+        call("scnattn_stem_bn_relu_maxpool", stream_of(x), N, Hz, Wz, 64, ptr(z), ptr(ss), ptr(out), 0)
         a = torch.relu(z.view(N, Hz, Wz, 64) * ss[:, 0] + ss[:, 1]).permute(0, 3, 1, 2)
         pref = F.max_pool2d(a, 3, 2, 1).permute(0, 2, 3, 1).reshape(-1, 64)
         assert torch.allclose(out, pref, rtol=1e-6, atol=1e-6), ("stem pool", N, H, W, (out - pref).abs().max().item())
@@ -375,7 +527,7 @@ def time3():
     part = torch.empty(2, 64, (nt + 3) & ~3, device=dev); ss = torch.rand(64, 2, device=dev)
     c0 = t_us(lambda: call("scnattn_stem_conv7", stream_of(x), N, H, H, ptr(x), *x.stride(), ptr(w), *w.stride(), ptr(z), ptr(part), None))
     c1 = t_us(lambda: F.conv2d(x, w, stride=2, padding=3))
-    p0 = t_us(lambda: call("scnattn_stem_bn_relu_maxpool", stream_of(x), N, 128, 128, 64, ptr(z), ptr(ss), ptr(out)))
+    p0 = t_us(lambda: call("scnattn_stem_bn_relu_maxpool", stream_of(x), N, 128, 128, 64, ptr(z), ptr(ss), ptr(out), 0))
     z4 = z.view(N, 128, 128, 64).permute(0, 3, 1, 2)
     p1 = t_us(lambda: F.max_pool2d(z4, 3, 2, 1))
     print("stem: conv7 + stats %7.1f us (miopen conv %7.1f) (%5.1f TF) | bn+relu+maxpool %7.1f us (aten maxpool alone %7.1f)"
@@ -521,5 +673,9 @@ if __name__ == "__main__":
         checkstem()
     if what in ("checkbn", "all3"):
         checkbn()
+    if what in ("check16", "all16"):
+        check16()
+    if what in ("time16", "all16"):
+        time16()
     if what in ("time3", "all3"):
         time3()
