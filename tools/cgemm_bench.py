@@ -461,6 +461,33 @@ def time16():
         print("%-5s | %s" % (name, " ".join("%7.1f" % v for v in t)), flush=True)
 
 
+def timebn():
+    """Finalize-on-load BatchNorm kernels on the trunk's map shapes (B = 32, fp32 and bf16 maps): us and achieved TB/s on the
+    algorithmic bytes (maps read + written)."""
+    BF = torch.bfloat16
+    print("BN kernels: shape | apply_fin(relu) apply_fin(res+relu) bwd_reduce(+g) bwd_dx_fin | TB/s of each")
+    for dt in (torch.float32, BF):
+        for name, R, Cn in [("l2 p", 32768, 128), ("l2 4p", 32768, 512), ("l3 p", 8192, 256), ("l3 4p", 8192, 1024), ("l4 p", 2048, 512),
+                            ("l4 4p", 2048, 2048), ("l1 4p", 131072, 256)]:
+            z = torch.randn(R, Cn, device=dev).to(dt); res = torch.randn(R, Cn, device=dev).to(dt); y = torch.empty_like(z)
+            ga = torch.rand(Cn, device=dev) + 0.5; be = torch.randn(Cn, device=dev) * 0.1
+            mt = lib().scnattn_cgemm_row_tiles(R); ld = lib().scnattn_cgemm_stat_ld(R)
+            part = torch.rand(2, Cn, ld, device=dev); shift = torch.zeros(Cn, device=dev); stt = torch.rand(2, Cn, device=dev) + 0.5
+            bf = 1 if dt == BF else 0
+            es = 2 if bf else 4
+            f1 = lambda r: t_us(lambda: call("scnattn_bn_apply_fin", stream_of(z), R, Cn, ptr(z), ptr(res) if r else None, bf, ptr(part), ld, mt, ptr(shift), 1e-5, 0.1,
+                                            ptr(ga), ptr(be), 1, ptr(y), ptr(stt[0]), ptr(stt[1]), None, None, None))
+            bpart = torch.empty(2 * Cn * 260, device=dev); gout = torch.empty_like(z); nch = C.c_int(0); dgb = torch.empty(2, Cn, device=dev)
+            t_r = t_us(lambda: call("scnattn_bn_bwd_reduce", stream_of(z), R, Cn, ptr(res), ptr(y), ptr(z), bf, ptr(stt[0]), ptr(stt[1]), 1, ptr(bpart), 260, ptr(gout), C.byref(nch)))
+            ldb = (nch.value + 3) & ~3
+            t_d = t_us(lambda: call("scnattn_bn_bwd_dx_fin", stream_of(z), R, Cn, ptr(gout), ptr(z), bf, ptr(stt[0]), ptr(stt[1]), ptr(ga), ptr(bpart), ldb, nch.value,
+                                    ptr(dgb[0]), ptr(dgb[1]), ptr(y)))
+            ts = [f1(False), f1(True), t_r, t_d]
+            maps = [2, 3, 4, 3]
+            print("%-5s %-6s (%6d x %4d) | %s | %s" % ("bf16" if bf else "fp32", name, R, Cn, " ".join("%6.1f" % t for t in ts),
+                                                        " ".join("%5.2f" % (m * R * Cn * es / t / 1e6) for m, t in zip(maps, ts))), flush=True)
+
+
 def checkstem():
     g = torch.Generator(device="cpu").manual_seed(2)
     for (N, H, W, cl_x, cl_w) in [(2, 64, 64, False, True), (3, 50, 70, True, True), (1, 33, 17, False, False), (32, 256, 256, True, True)]:
@@ -673,6 +700,8 @@ if __name__ == "__main__":
         checkstem()
     if what in ("checkbn", "all3"):
         checkbn()
+    if what == "timebn":
+        timebn()
     if what in ("check16", "all16"):
         check16()
     if what in ("time16", "all16"):
