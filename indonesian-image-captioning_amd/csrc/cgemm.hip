@@ -36,6 +36,10 @@
 //     cannot fill 256 CUs.
 #include "common.h"
 #include "kernels.h"
+#include <map>
+#include <mutex>
+#include <type_traits>
+#include <utility>
 
 namespace scn {
 
@@ -70,6 +74,8 @@ struct CArgs {
     int ldp;                      // leading dimension of stat_partial: cdiv(M, 64) rounded up to 4 (cgemm_stat_ld)
     const float* ez; const float* emean; const float* einvstd; const float* egamma; const float* ebeta;  // mask pass
     long ldz;
+    int* cnt;                     // in-launch split-K combine: one arrival counter per (batch, tile), zero at rest; null -> two launches
+    int comb;                     // 1: write-through (sc1) slab stores, 2: plain slab stores + agent release
 };
 
 // output row (n, ho, wo) of a strided 1x1 convolution -> input row (n, ho*s, wo*s)
@@ -91,6 +97,10 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned by
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, 0);
 }
 
+__device__ __forceinline__ void buf_store4_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, f32x4 v) {   // write-through
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, 16);
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
@@ -105,7 +115,11 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // 64-channel maps of layer1).  With the 2 x 2 layout half of such a tile's MFMAs multiply zero columns.
 // A_MC / B_MC: operand stored with its m / n dimension contiguous ([K][M] / [K][N]); otherwise k contiguous.
 // PRO: 0 none, 1 relu(a*scale[k]+shift[k]) on a KC A operand, 2 relu(b*scale[n]+shift[n]) on a MC B operand.
-// EPI: 0 plain (alpha, beta, bias, rowmask), 1 plain store + column statistics.
+// EPI: 0 plain (alpha, beta, bias, rowmask), 1 plain store + column statistics, 2 ReLU mask of the consumer BatchNorm
+//      recomputed from its pre-activation z + the two column sums of its backward (g, g*xhat), g stored.
+//      A split product (S > 1) with arrival counters (g.cnt) applies its epilogue IN THE SAME LAUNCH: every slice writes
+//      its slab, takes a ticket, and the workgroup that draws the last ticket of a tile sums the S slabs in slab order
+//      (deterministic) and finishes the tile -- no second launch, no second trip of the product through HBM.
 // GATHER: rows of a KC A operand or k-rows of a MC B operand are gathered (strided 1x1 convolution).
 // VEC: the output takes 16-byte row stores.
 // C3: 3x3 convolution (pad 1) as an implicit GEMM -- no im2col buffer, the taps are a walk over K (forward, dgrad) or a
@@ -422,18 +436,211 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
     };
     const int mw0 = m0 + wm * 32 * RB;             // first row of this wave
 
-    if (g.S > 1) {   // split-K: raw alpha-scaled partial tile; the reduce kernels apply the epilogue
+    // ---- finishing a 32-row block in ROW layout (lane = columns c4 .. c4+3 of rows it*4 + rl, it = 0 .. 7): the in-launch
+    // split-K combine (all epilogues) and the un-split mask epilogue (EPI 2) ------------------------------------------------
+    [[maybe_unused]] f32x4 kv0 = {0.f, 0.f, 0.f, 0.f}, kv1 = kv0, kv2 = kv0, kv3 = kv0;   // per-column constants of the epilogue
+    const bool folded = EPI == 2 && g.pro_ss != nullptr;   // the mask of the function the forward pass evaluated: relu(fma(z, scale, shift))
+    [[maybe_unused]] float fs1[4] = {0.f, 0.f, 0.f, 0.f}, fs2[4] = {0.f, 0.f, 0.f, 0.f};
+    [[maybe_unused]] f32x4 xv[8];            // EPI 0: C rows (beta != 0); EPI 2: z rows
+    [[maybe_unused]] float mk[8];
+    const bool f_use_c = EPI == 0 && g.beta != 0.f, f_use_m = EPI == 0 && g.rowmask != nullptr;
+    const __amdgpu_buffer_rsrc_t f_crs = make_rsrc(C, VEC ? (unsigned)(((long)(g.M - 1) * g.ldc + g.N) * 4) : 0u);
+    const __amdgpu_buffer_rsrc_t f_zrs = make_rsrc(g.ez, (VEC && EPI == 2) ? (unsigned)(((long)(g.M - 1) * g.ldz + g.N) * 4) : 0u);
+    const __amdgpu_buffer_rsrc_t f_mrs = make_rsrc(g.rowmask, f_use_m ? (unsigned)g.M * 4u : 0u);
+    auto out_off = [&](int m) -> unsigned { return (m < g.M && cok) ? (unsigned)(((long)m * g.ldc + ncol) * 4) + opq : OOB_OFF; };
+    auto finish_setup = [&]() {
+        if (!cok) return;
+        if (EPI == 0 && g.bias) kv0 = *reinterpret_cast<const f32x4*>(g.bias + ncol);
+        if (EPI == 1 && g.stat_shift) kv0 = *reinterpret_cast<const f32x4*>(g.stat_shift + ncol);
+        if (EPI == 2) {
+            kv0 = *reinterpret_cast<const f32x4*>(g.emean + ncol);
+            kv1 = *reinterpret_cast<const f32x4*>(g.einvstd + ncol);
+            if (folded) {
+                const f32x4 t0 = *reinterpret_cast<const f32x4*>(g.pro_ss + 2 * ncol), t1 = *reinterpret_cast<const f32x4*>(g.pro_ss + 2 * ncol + 4);
+                kv2 = f32x4{t0[0], t0[2], t1[0], t1[2]};
+                kv3 = f32x4{t0[1], t0[3], t1[1], t1[3]};
+            } else {
+                kv2 = *reinterpret_cast<const f32x4*>(g.egamma + ncol);
+                kv3 = *reinterpret_cast<const f32x4*>(g.ebeta + ncol);
+            }
+        }
+    };
+    // NV rows (it0 .. it0+NV-1 of the block's eight) per call: 8 when the accumulators are dead (combine), 4 while the
+    // other 32-row block still sits in them (un-split mask epilogue) -- register pressure
+    auto finish_load = [&](int i, int it0, auto nv) {   // issue the side loads (they fly while the product is fetched / dumped)
+        constexpr int NV = decltype(nv)::value;
+        const int mb = mw0 + i * 32;
+        if (f_use_c) {
+#pragma unroll
+            for (int u = 0; u < NV; ++u) xv[u] = buf_load4(f_crs, out_off(mb + (it0 + u) * 4 + rl));
+        }
+        if (f_use_m) {
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const int m = mb + (it0 + u) * 4 + rl;
+                mk[u] = buf_load(f_mrs, m < g.M ? (unsigned)m * 4u + opq : OOB_OFF);
+            }
+        }
+        if (EPI == 2) {
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const int m = mb + (it0 + u) * 4 + rl;
+                xv[u] = buf_load4(f_zrs, (m < g.M && cok) ? (unsigned)(((long)m * g.ldz + ncol) * 4) + opq : OOB_OFF);
+            }
+        }
+    };
+    auto finish_block = [&](int i, int it0, auto& v) {
+        constexpr int NV = sizeof(v) / sizeof(v[0]);
+        const int mb = mw0 + i * 32;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int m = mb + (it0 + u) * 4 + rl;
+            if (EPI == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[u][q] += kv0[q];
+                if (f_use_c) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[u][q] = fmaf(g.beta, xv[u][q], v[u][q]);
+                }
+                if (f_use_m && mk[u] == 0.f) v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else if (EPI == 1) {
+                if (m < g.M) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float d = v[u][q] - kv0[q];
+                        fs1[q] += d;
+                        fs2[q] = fmaf(d, d, fs2[q]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float z = xv[u][q], xh = (z - kv0[q]) * kv1[q];
+                    const bool on = fmaf(folded ? z : xh, kv2[q], kv3[q]) > 0.f;
+                    v[u][q] = on ? v[u][q] : 0.f;
+                    fs1[q] += v[u][q];
+                    fs2[q] = fmaf(v[u][q], xh, fs2[q]);
+                }
+            }
+            buf_store4(f_crs, out_off(m), v[u]);
+        }
+    };
+    auto finish_stats = [&]() {              // column sums of this wave's rows -> one partial per 64-row block
+        if (EPI == 0) return;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            fs1[q] += __shfl_xor(fs1[q], 16, 64); fs1[q] += __shfl_xor(fs1[q], 32, 64);
+            fs2[q] += __shfl_xor(fs2[q], 16, 64); fs2[q] += __shfl_xor(fs2[q], 32, 64);
+        }
+        if (MI == 2) {
+            if (lane < 16 && cok && mw0 < g.M) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float* p = g.stat_partial + (long)(ncol + q) * g.ldp + (tm * 2 + wm);
+                    p[0] = fs1[q];
+                    p[(long)g.N * g.ldp] = fs2[q];
+                }
+            }
+            return;
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                colsum[(wm * 2 + 0) * TN + wn * 64 + c4 + q] = fs1[q];
+                colsum[(wm * 2 + 1) * TN + wn * 64 + c4 + q] = fs2[q];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (MI == 1) {
+            if (tid < TN && n0 + tid < g.N) {
+                float* p = g.stat_partial + (long)(n0 + tid) * g.ldp + tm;
+                p[0] = colsum[0 * TN + tid] + colsum[2 * TN + tid];
+                p[(long)g.N * g.ldp] = colsum[1 * TN + tid] + colsum[3 * TN + tid];
+            }
+        } else {      // 4 x 1 waves: (0,1) form the tile's first 64-row statistics block, (2,3) its second
+            const int blk = tid >> 6, col = tid & 63;
+            if (tid < 128 && n0 + col < g.N && m0 + blk * 64 < g.M) {
+                float* p = g.stat_partial + (long)(n0 + col) * g.ldp + (tm * 2 + blk);
+                p[0] = colsum[((2 * blk) * 2 + 0) * TN + col] + colsum[((2 * blk + 1) * 2 + 0) * TN + col];
+                p[(long)g.N * g.ldp] = colsum[((2 * blk) * 2 + 1) * TN + col] + colsum[((2 * blk + 1) * 2 + 1) * TN + col];
+            }
+        }
+    };
+
+    if (g.S > 1) {   // split-K: raw alpha-scaled partial tile; the combine below or the reduce kernels apply the epilogue
         if constexpr (VEC) {
+            const bool wt = g.cnt && g.comb == 1;
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
                 dump_half(i, 0.f, 0.f);
+                if (wt) {
 #pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const int row = it * 4 + rl;
-                    buf_store4(ors, row_off(mw0 + i * 32 + row), *reinterpret_cast<const f32x4*>(lw + row * 64 + c4));
+                    for (int it = 0; it < 8; ++it) {
+                        const int row = it * 4 + rl;
+                        buf_store4_sc1(ors, row_off(mw0 + i * 32 + row), *reinterpret_cast<const f32x4*>(lw + row * 64 + c4));
+                    }
+                } else {
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const int row = it * 4 + rl;
+                        buf_store4(ors, row_off(mw0 + i * 32 + row), *reinterpret_cast<const f32x4*>(lw + row * 64 + c4));
+                    }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // reads done before the next block overwrites
             }
+            if (!g.cnt) return;
+            // ---- in-launch combine (cdna_hip_programming.md, in-launch split-K reduction; MI355X_MICROARCH.md, valid forms):
+            // every storing wave drains its stores, the workgroup meets, ONE lane publishes (write-through slabs need no
+            // write-back; plain ones an agent release) and takes the ticket; the last arriver acquires and reads the slabs.
+            int* const flag = reinterpret_cast<int*>(lds + 4 * 2048 + 8 * TN);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                if (g.comb != 1) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                int* const ticket = g.cnt + zb * ntiles + bid;
+                const int old = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = old == g.S - 1;
+                if (last) {
+                    __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // zero at rest for the next launch
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                *flag = last;
+            }
+            __syncthreads();
+            if (!*flag) return;
+            const __amdgpu_buffer_rsrc_t srs = make_rsrc(g.ws + ((long)zb * g.S * g.M) * g.N, (unsigned)(((long)g.S * g.M * g.N) * 4));
+            finish_setup();
+#pragma unroll 1
+            for (int i = 0; i < RB; ++i) {
+                finish_load(i, 0, std::integral_constant<int, 8>{});
+                f32x4 v[8];
+#pragma unroll
+                for (int it = 0; it < 8; ++it) v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int mb = mw0 + i * 32;
+                unsigned so[8];
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int m = mb + it * 4 + rl;
+                    so[it] = (m < g.M && cok) ? (unsigned)(((long)m * g.N + ncol) * 4) + opq : OOB_OFF;
+                }
+                const unsigned sstep = (unsigned)((long)g.M * g.N * 4);
+                for (int s0 = 0; s0 < g.S; ++s0) {        // slab order: the sum does not depend on who arrived last
+                    f32x4 t[8];
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) t[it] = buf_load4(srs, so[it] == OOB_OFF ? OOB_OFF : so[it] + (unsigned)s0 * sstep);
+#pragma unroll
+                    for (int it = 0; it < 8; ++it)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[it][q] += t[it][q];
+                }
+                finish_block(i, 0, v);
+            }
+            finish_stats();
         } else {
 #pragma unroll
             for (int i = 0; i < RB; ++i)
@@ -447,6 +654,26 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
                     }
                 }
         }
+        return;
+    }
+
+    if constexpr (VEC && EPI == 2) {      // un-split product feeding a BatchNorm backward: mask + sums in the epilogue
+        finish_setup();
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            finish_load(i, 0, std::integral_constant<int, 4>{});
+            dump_half(i, 0.f, 0.f);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(lw + ((h * 4 + u) * 4 + rl) * 64 + c4);
+                finish_block(i, h * 4, v);
+                if (h == 0) finish_load(i, 4, std::integral_constant<int, 4>{});
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        finish_stats();
         return;
     }
 
@@ -744,6 +971,30 @@ constexpr int CG_MAX_SPLIT = 128;   // wgrad of the early layers: 4 output tiles
 int g_cgemm_target = 512;     // aim for this many workgroups (tiles x splits) when the tile grid alone is < 256
 int g_cgemm_kmin = 128;       // at least this much K per split
 int g_cgemm_mi = 0;           // 0: pick the row tile (64 or 128) per shape; 1 / 2: force it (tuning)
+int g_cgemm_combine = 1;      // split-K epilogue inside the launch: 0 off (second launch), 1 write-through slabs, 2 plain slabs + release
+int g_cgemm_combine_max = 16; // deepest split the last arriver sums alone (deeper: the reduce launch spreads it over the chip)
+
+namespace {
+// Arrival counters of the in-launch combine: one array per (device, stream), zero at rest (the last arriver of a tile
+// resets its counter), so launches of ONE stream -- which never overlap -- share it and concurrent streams never do.
+constexpr int CNT_N = 1 << 16;
+std::mutex g_cnt_mu;
+std::map<std::pair<int, hipStream_t>, int*> g_cnt;
+int* stream_counters(hipStream_t st) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_cnt_mu);
+    auto it = g_cnt.find({dev, st});
+    if (it != g_cnt.end()) return it->second;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;   // no allocation inside a capture
+    int* p = nullptr;
+    if (hipMalloc(&p, CNT_N * sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, CNT_N * sizeof(int)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return nullptr; }
+    g_cnt[{dev, st}] = p;
+    return p;
+}
+}  // namespace
 
 bool cgemm_supported(bool tA, bool tB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                      long sA, long sB) {
@@ -763,7 +1014,9 @@ namespace {
 template <int MI, bool AMC, bool BMC, int PRO, bool G>
 void launch_ev(hipStream_t st, dim3 grid, const CArgs& g, int kepi, bool vec) {
     dim3 block(256);
-    if (kepi == 1) hipLaunchKernelGGL((cgemm_kernel<MI, AMC, BMC, PRO, 1, G, true>), grid, block, 0, st, g);
+    if (kepi == 2) {       // mask epilogue: the d-input products only (host-checked)
+        if constexpr (!AMC && BMC && PRO == 0 && !G) hipLaunchKernelGGL((cgemm_kernel<MI, false, true, 0, 2, false, true>), grid, block, 0, st, g);
+    } else if (kepi == 1) hipLaunchKernelGGL((cgemm_kernel<MI, AMC, BMC, PRO, 1, G, true>), grid, block, 0, st, g);
     else if (vec)  hipLaunchKernelGGL((cgemm_kernel<MI, AMC, BMC, PRO, 0, G, true>), grid, block, 0, st, g);
     else           hipLaunchKernelGGL((cgemm_kernel<MI, AMC, BMC, PRO, 0, G, false>), grid, block, 0, st, g);
 }
@@ -775,7 +1028,8 @@ int launch_conv3(hipStream_t st, dim3 grid, const CArgs& g, int c3, int kepi) {
         if (kepi == 1) hipLaunchKernelGGL((cgemm_kernel<MI, false, false, 0, 1, false, true, 1>), grid, block, 0, st, g);
         else           hipLaunchKernelGGL((cgemm_kernel<MI, false, false, 0, 0, false, true, 1>), grid, block, 0, st, g);
     } else if (c3 == 2) {
-        hipLaunchKernelGGL((cgemm_kernel<MI, false, true, 0, 0, false, true, 2>), grid, block, 0, st, g);
+        if (kepi == 2) hipLaunchKernelGGL((cgemm_kernel<MI, false, true, 0, 2, false, true, 2>), grid, block, 0, st, g);
+        else           hipLaunchKernelGGL((cgemm_kernel<MI, false, true, 0, 0, false, true, 2>), grid, block, 0, st, g);
     } else if (c3 == 4) {
         hipLaunchKernelGGL((cgemm_kernel<MI, false, true, 0, 0, false, true, 4>), grid, block, 0, st, g);
     } else {
@@ -904,8 +1158,16 @@ int cgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
         g.ez = ex->ez; g.emean = ex->emean; g.einvstd = ex->einvstd; g.egamma = ex->egamma; g.ebeta = ex->ebeta; g.ldz = ex->ldz;
     }
     dim3 grid(mt * nt, c3 == 4 ? 4 : batch * S), block(256);
-    // in-kernel: plain or statistics; the mask pass (epi 2) and every epilogue of a split product run in the second launch
-    const int kepi = (S > 1 || epi == 2) ? 0 : epi;
+    // The epilogue runs inside the launch: from the accumulators of an un-split product, or -- split product -- by the
+    // workgroup that arrives last at its tile (arrival counters of this stream).  Second launch (creduce / cstats) only
+    // for what the in-launch forms do not cover: scalar stores, very deep splits, a mask epilogue on another layout.
+    const bool epi_in = epi != 2 || (!tA && !tB && pro == 0 && !gather && c3 == 0) || c3 == 2;
+    int* cnt = nullptr;
+    if (S > 1 && g_cgemm_combine && S <= g_cgemm_combine_max && vec && epi_in && (epi == 0 || !tA) && tiles <= CNT_N &&
+        (long)S * M * N * 4 < 0x7fffffffL)
+        cnt = stream_counters(st);
+    g.cnt = cnt; g.comb = g_cgemm_combine;
+    const int kepi = (S > 1 && !cnt) ? 0 : (epi_in ? epi : 0);
     if (c3) {
         SCN_ARG(vec, "cgemm: 3x3 mode needs 16-byte row stores");
         if (mi == 4) SCN_TRY(launch_conv3<4>(st, grid, g, c3, kepi));
@@ -915,7 +1177,7 @@ int cgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
     else if (mi == 2) SCN_TRY(launch_layout<2>(st, grid, g, tA, tB, pro, kepi, gather, vec));
     else SCN_TRY(launch_layout<1>(st, grid, g, tA, tB, pro, kepi, gather, vec));
     SCN_LAUNCH_CHECK();
-    if (S > 1 || epi == 2) {
+    if ((S > 1 && !cnt) || (epi == 2 && !epi_in)) {
         if (epi == 0) {
             if (vec) hipLaunchKernelGGL(creduce_kernel<true>, dim3(cdiv((long)M * N / 4, 256), batch), block, 0, st, g);
             else     hipLaunchKernelGGL(creduce_kernel<false>, dim3(cdiv((long)M * N, 256), batch), block, 0, st, g);

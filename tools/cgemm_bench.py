@@ -19,11 +19,21 @@ dev = torch.device("cuda:0")
 WS = torch.empty(48 << 20, device=dev)
 
 
+_BLK = None
+
+
 def t_us(fn, it=20):
+    """GPU time per call.  The calls are enqueued BEHIND a few milliseconds of other work, so the stream never waits for
+    the host (a ctypes call costs 20-45 us of Python here -- more than many of the kernels measured)."""
+    global _BLK
+    if _BLK is None:
+        _BLK = (torch.randn(8192, 8192, device=dev), torch.randn(8192, 8192, device=dev), torch.empty(8192, 8192, device=dev))
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(1 + it // 40):
+        torch.mm(_BLK[0], _BLK[1], out=_BLK[2])        # ~10 ms of fp32 work each
     a.record()
     for _ in range(it):
         fn()
@@ -131,6 +141,93 @@ def check():
     o = cgemm(a, b, True, True, torch.empty(200, 60, device=dev), 200, 60, 96)
     e = rel(o, a.double().t() @ b.double().t()); assert e < 3e-6, ("TT", e)
     print("check ok, worst rel err %.2e" % worst, flush=True)
+
+
+def comb():
+    """In-launch split-K combine (cgemm_combine 1: write-through slabs, 2: plain slabs + agent release) against the two-launch
+    protocol (0): the outputs must be BIT-identical (same slab order), also while a second stream keeps the chip unevenly
+    busy and the consumer's caches warm; then the time per launch of the trunk's split products under each protocol."""
+    g = torch.Generator(device="cpu").manual_seed(5)
+    side = torch.cuda.Stream()
+    junk_a = torch.randn(3000, 1536, device=dev); junk_b = torch.randn(1536, 1000, device=dev); junk_o = torch.empty(3000, 1000, device=dev)
+    nbad = 0
+    for (R, Cin, Cout) in [(8192, 1024, 256), (2048, 2048, 512), (8192, 256, 1024), (1000, 512, 132), (32768, 512, 128)]:
+        x = torch.randn(R, Cin, generator=g).to(dev); w = (torch.randn(Cout, Cin, generator=g) * 0.1).to(dev)
+        dy = torch.randn(R, Cout, generator=g).to(dev); z = torch.randn(R, Cin, generator=g).to(dev)
+        mu = (0.1 * torch.randn(Cin, generator=g)).to(dev); isd = (1 + 0.2 * torch.rand(Cin, generator=g)).to(dev)
+        ga = (1 + 0.3 * torch.randn(Cin, generator=g)).to(dev); be = (0.2 * torch.randn(Cin, generator=g)).to(dev)
+        sc = (1 + 0.5 * torch.randn(Cin, generator=g)).to(dev); sh = (0.2 * torch.randn(Cin, generator=g)).to(dev)
+        ss = torch.stack([sc, sh], dim=1).contiguous()
+        mt = lib().scnattn_cgemm_row_tiles(R)
+        for split in (2, 3, 4, 8):
+            if Cin // split < 16 or Cout // split < 16 or split * R * max(Cin, Cout) > WS.numel():
+                continue
+            outs = {}
+            for mode in (0, 1, 2):
+                SF.set_option("cgemm_combine", mode)
+                for rep in range(6 if mode else 1):
+                    with torch.cuda.stream(side):            # uneven background load, different every repetition
+                        for _ in range(1 + rep):
+                            torch.mm(junk_a, junk_b, out=junk_o)
+                    pf = torch.full((2, Cout, lib().scnattn_cgemm_stat_ld(R)), float("nan"), device=dev)
+                    y = cgemm(x, w, False, True, torch.empty(R, Cout, device=dev), R, Cout, Cin,
+                              ConvExtra(pro=1, epi=1, pro_ss=ss.data_ptr(), stat_partial=pf.data_ptr(), force_split=split))
+                    pm = torch.full((2, Cin, lib().scnattn_cgemm_stat_ld(R)), float("nan"), device=dev)
+                    gk = cgemm(dy, w, False, False, torch.empty(R, Cin, device=dev), R, Cin, Cout,
+                               ConvExtra(epi=2, stat_partial=pm.data_ptr(), ez=z.data_ptr(), emean=mu.data_ptr(), einvstd=isd.data_ptr(),
+                                         egamma=ga.data_ptr(), ebeta=be.data_ptr(), ldz=Cin, force_split=split))
+                    dx0 = torch.randn(R, Cin, generator=g).to(dev)
+                    dxb = cgemm(dy, w, False, False, dx0.clone(), R, Cin, Cout, ConvExtra(force_split=split), beta=1.0)
+                    dw = cgemm(dy, x, True, False, torch.empty(Cout, Cin, device=dev), Cout, Cin, R, ConvExtra(force_split=split))
+                    torch.cuda.synchronize()
+                    cur = dict(y=y, gk=gk, dw=dw, sf=pf[:, :, :mt].sum(2), sm=pm[:, :, :mt].sum(2))
+                    if mode == 0:
+                        outs = cur
+                        outs["dxb0"] = dxb - dx0
+                        yr = torch.relu(x.double() * sc.double() + sh.double()) @ w.double().t()
+                        assert rel(y, yr) < 3e-6
+                    else:
+                        for k in ("y", "gk", "dw"):
+                            if not torch.equal(cur[k], outs[k]):
+                                nbad += 1
+                                print("MISMATCH", (R, Cin, Cout), "split", split, "mode", mode, "rep", rep, k,
+                                      int((cur[k] != outs[k]).sum()), "elements", flush=True)
+                        for k in ("sf", "sm"):
+                            e = rel(cur[k], outs[k])
+                            if not e < 2e-5:
+                                nbad += 1
+                                print("STATS", (R, Cin, Cout), split, mode, rep, k, e, flush=True)
+                        e = rel(dxb - dx0, outs["dxb0"])
+                        if not e < 1e-5:
+                            nbad += 1
+                            print("BETA", (R, Cin, Cout), split, mode, rep, e, flush=True)
+    assert nbad == 0, "in-launch combine differs from the two-launch protocol"
+    print("combine: bit-identical to the two-launch protocol on every shape / split / repetition", flush=True)
+    shapes = [("l1.conv1", 64, 64, 256, 64), ("l1.conv3", 64, 64, 64, 256), ("l2.conv1", 32, 32, 512, 128),
+              ("l2.conv3", 32, 32, 128, 512), ("l3.conv1", 16, 16, 1024, 256), ("l3.conv3", 16, 16, 256, 1024),
+              ("l4.conv1", 8, 8, 2048, 512), ("l4.conv3", 8, 8, 512, 2048)]
+    B = 32
+    print("policy split, us per product under cgemm_combine 0 / 1 / 2:  fwd+pro+stats | dgrad+mask | dgrad beta=1 | wgrad", flush=True)
+    for name, H, W, Cin, Cout in shapes:
+        R = B * H * W
+        x2 = torch.randn(R, Cin, device=dev); w2 = 0.1 * torch.randn(Cout, Cin, device=dev); dy2 = torch.randn(R, Cout, device=dev)
+        y2 = torch.empty(R, Cout, device=dev); dx2 = torch.empty(R, Cin, device=dev); dw2 = torch.empty(Cout, Cin, device=dev)
+        sc = torch.rand(Cin, device=dev) + 0.5; sh = torch.randn(Cin, device=dev) * 0.1
+        ss = torch.stack([sc, sh], dim=1).contiguous()
+        part = torch.empty(2, max(Cin, Cout), lib().scnattn_cgemm_stat_ld(R), device=dev)
+        z = torch.randn(R, Cin, device=dev); v = torch.rand(Cin, device=dev) + 0.5
+        exf = ConvExtra(pro=1, epi=1, pro_ss=ss.data_ptr(), stat_partial=part.data_ptr())
+        exd = ConvExtra(epi=2, stat_partial=part.data_ptr(), ez=z.data_ptr(), emean=sh.data_ptr(), einvstd=v.data_ptr(),
+                        egamma=v.data_ptr(), ebeta=sh.data_ptr(), ldz=Cin)
+        row = []
+        for mode in (0, 1, 2):
+            SF.set_option("cgemm_combine", mode)
+            row.append((t_us(lambda: cgemm(x2, w2, False, True, y2, R, Cout, Cin, exf)),
+                        t_us(lambda: cgemm(dy2, w2, False, False, dx2, R, Cin, Cout, exd)),
+                        t_us(lambda: cgemm(dy2, w2, False, False, dx2, R, Cin, Cout, None, beta=1.0)),
+                        t_us(lambda: cgemm(dy2, x2, True, False, dw2, Cout, Cin, R))))
+        print("%-9s %6d %5d %5d | %s" % (name, R, Cin, Cout, " | ".join(" ".join("%6.1f" % row[m][k] for m in range(3)) for k in range(4))), flush=True)
+    SF.set_option("cgemm_combine", 1)
 
 
 def timeit():
@@ -692,6 +789,8 @@ if __name__ == "__main__":
         check()
     if what in ("time", "all"):
         timeit()
+    if what == "comb":
+        comb()
     if what == "ab":
         ab()
     if what in ("check3", "all3"):
