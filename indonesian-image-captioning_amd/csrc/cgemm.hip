@@ -133,7 +133,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 //       it gathers dY[(n, ho' + oh, wo' + ow)] (oh = 1 for the tap dh = 0 of an odd row, else 0) and is stored at d-input
 //       row (n, 2 ho' + ph, 2 wo' + pw).
 template <int MI, bool A_MC, bool B_MC, int PRO, int EPI, bool GATHER, bool VEC, int C3 = 0>
-__global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
+__global__ __launch_bounds__(256, MI == 2 ? 2 : 3) void cgemm_kernel(CArgs g) {
     __shared__ __attribute__((aligned(16))) float lds[NSTAGE * STAGE_F];
     constexpr bool W41 = (MI == 4);
     constexpr int RB = W41 ? 1 : MI;                   // 32-row MFMA blocks per wave
@@ -223,12 +223,15 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
         }
     }
 
-    auto issue = [&](int kt, int stage) {     // LDS-DMA of k-step kt into ring slot `stage`
+    // LDS-DMA of k-step kt into ring slot `stage`, one 1-KiB piece per call: P < ACH the A chunks, then the two B chunks,
+    // then (PRO 1) the scale/shift table.  A k-step past the end (k0 >= Kend) zero-fills: the pipeline below never branches.
+    auto issue_piece = [&](int kt, int stage, auto pc) {
+        constexpr int P = decltype(pc)::value;
         float* sa = lds + stage * STAGE_F;
         float* sb = sa + TILE_F;
         const int k0 = kbeg + kt * TK;
-#pragma unroll
-        for (int c = 0; c < ACH; ++c) {
+        if constexpr (P < ACH) {
+            constexpr int c = P;
             const int chunk = wave * ACH + c;
             unsigned va;
             if (C3 == 4) {                  // class tap t = (th, tw): source pixel (ho' + oh, wo' + ow)
@@ -252,8 +255,8 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
             }
             dma16(ars, sa + chunk * 256, va);
         }
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        if constexpr (P >= ACH && P < ACH + 2) {
+            constexpr int c = P - ACH;
             const int chunk = wave * 2 + c;
             unsigned vb;
             if (!B_MC) {
@@ -284,11 +287,19 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
             }
             dma16(brs, sb + chunk * 256, vb);
         }
-        if (PRO == 1) {   // this wave's private copy of {scale, shift}[k0 .. k0+15] (32 floats, one instruction)
+        if constexpr (PRO == 1 && P == ACH + 2) {   // this wave's private copy of {scale, shift}[k0 .. k0+15] (32 floats, one instruction)
             float* sx = sa + 2 * TILE_F + wave * 64;
             const int kk = k0 + (lane >> 1);
             dma4(srs, sx, (lane < 32 && kk < Kend) ? (unsigned)(2 * k0 + lane) * 4u : OOB_OFF);
         }
+    };
+
+    auto issue = [&](int kt, int stage) {
+        issue_piece(kt, stage, std::integral_constant<int, 0>{});
+        if constexpr (LPT > 1) issue_piece(kt, stage, std::integral_constant<int, 1>{});
+        if constexpr (LPT > 2) issue_piece(kt, stage, std::integral_constant<int, 2>{});
+        if constexpr (LPT > 3) issue_piece(kt, stage, std::integral_constant<int, 3>{});
+        if constexpr (LPT > 4) issue_piece(kt, stage, std::integral_constant<int, 4>{});
     };
 
     f32x16 acc[RB][2];
@@ -334,23 +345,22 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
 
-    if (nk > 0) issue(0, 0);
-    if (nk > 1) issue(1, 1);
-    if (nk > 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
-    if (PRO == 1 && nk > 0) prologue_in_lds(0);
-    __builtin_amdgcn_s_barrier();
-
-    int stage = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 2 < nk) {
-            int s2 = stage + 2; if (s2 >= NSTAGE) s2 -= NSTAGE;
-            issue(kt + 2, s2);
-        }
-        const float* sa = lds + stage * STAGE_F;
+    // ---- the k-loop: a three-slot LDS ring fed by LDS-DMA PLUS two register sets of MFMA fragments, and NOTHING between
+    // two MFMA chains but one wait and one barrier.  K-step kt multiplies register set kt&1; INSIDE its MFMA chain, one
+    // piece per MFMA gap, travel (a) the fragments of k-step kt+1, LDS -> the other register set, and (b) the LDS-DMA pieces
+    // of k-step kt+3 into the slot k-step kt has just left (its fragments are in registers since the last barrier).  An
+    // LDS-DMA piece holds the wave's issue for 60-180 cycles (MI355X_MICROARCH.md, per-instruction constants): issued
+    // between the chains -- as a plain "prefetch, then compute" loop does -- three to five of them cost a workgroup that is
+    // alone on its CU (one wave per SIMD: the 8192-row maps of layer3) a quarter of the k-step; inside the chain they run in
+    // the shadow of the 64-cycle MFMAs.  End of k-step kt: this wave's pieces of k-step kt+2 have landed (kt+3 stays in
+    // flight), barrier -> kt+2 is published and every wave is done reading the slot of kt+1.
+    // The pipeline never branches: k-steps past the end are zero-fill DMAs into dead slots and fragment reads nobody uses.
+    auto load_piece = [&](int stg, auto pc, float (&a)[RB][8], float (&b)[2][8]) {
+        constexpr int P = decltype(pc)::value;
+        const float* sa = lds + stg * STAGE_F;
         const float* sb = sa + TILE_F;
-        float a[RB][8], b[2][8];
-#pragma unroll
-        for (int i = 0; i < RB; ++i) {
+        if constexpr (P < RB) {
+            constexpr int i = P;
             if (!A_MC) {
                 const int row = wm * 32 * RB + i * 32 + l31, sw = (row >> 2) & 3;
                 const f32x4 v0 = *reinterpret_cast<const f32x4*>(sa + row * 16 + (((2 * hh) ^ sw) << 2));
@@ -362,9 +372,8 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) a[i][q] = sa[(8 * hh + q) * TM + col];
             }
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        } else {
+            constexpr int j = P - RB;
             if (!B_MC) {
                 const int row = wn * 64 + j * 32 + l31, sw = (row >> 2) & 3;
                 const f32x4 v0 = *reinterpret_cast<const f32x4*>(sb + row * 16 + (((2 * hh) ^ sw) << 2));
@@ -377,29 +386,73 @@ __global__ __launch_bounds__(256, 3) void cgemm_kernel(CArgs g) {
                 for (int q = 0; q < 8; ++q) b[j][q] = sb[(8 * hh + q) * 128 + col];
             }
         }
+    };
+    auto load_frags = [&](int stg, float (&a)[RB][8], float (&b)[2][8]) {
+        load_piece(stg, std::integral_constant<int, 0>{}, a, b);
+        load_piece(stg, std::integral_constant<int, 1>{}, a, b);
+        load_piece(stg, std::integral_constant<int, 2>{}, a, b);
+        if constexpr (RB == 2) load_piece(stg, std::integral_constant<int, 3>{}, a, b);
+    };
+    auto slot = [](int kt) { return kt % NSTAGE; };
+    constexpr int NPL = RB + 2, NPC = NPL + LPT, NM = 16 * RB;     // load pieces, all pieces, MFMAs of a k-step
+    float fa0[RB][8], fb0[2][8], fa1[RB][8], fb1[2][8];
+    auto kstep = [&](int kt, float (&ac)[RB][8], float (&bc)[2][8], float (&an)[RB][8], float (&bn)[2][8]) {
+        const int s_next = slot(kt + 1), s_dma = slot(kt);
+        auto piece = [&](auto pc) {
+            constexpr int P = decltype(pc)::value;
+            if constexpr (P < NPL) load_piece(s_next, pc, an, bn);
+            else if constexpr (P < NPC) issue_piece(kt + 3, s_dma, std::integral_constant<int, P - NPL>{});
+        };
         if (PRO == 2) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int q = 0; q < 8; ++q) b[j][q] = fmaxf(fmaf(b[j][q], bsc[j], bsh[j]), 0.f);
+                for (int q = 0; q < 8; ++q) bc[j][q] = fmaxf(fmaf(bc[j][q], bsc[j], bsh[j]), 0.f);
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q)
 #pragma unroll
             for (int i = 0; i < RB; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
-        // the next tile must have landed (this wave's part) before the barrier that publishes it to the others;
-        // the tile after it stays in flight across the barrier
-        if (kt + 2 < nk) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
-        if (PRO == 1 && kt + 1 < nk) {
-            int s1 = stage + 1; if (s1 >= NSTAGE) s1 -= NSTAGE;
-            prologue_in_lds(s1);
-        }
+                for (int j = 0; j < 2; ++j) {
+                    const int m = (q * RB + i) * 2 + j;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[i][q], bc[j][q], acc[i][j], 0, 0, 0);
+                    // piece p rides behind MFMA p * NM / NPC: spread evenly over the chain, loads first
+                    if (m == 0 * NM / NPC) piece(std::integral_constant<int, 0>{});
+                    if (m == 1 * NM / NPC) piece(std::integral_constant<int, 1>{});
+                    if (m == 2 * NM / NPC) piece(std::integral_constant<int, 2>{});
+                    if (m == 3 * NM / NPC) piece(std::integral_constant<int, 3>{});
+                    if (m == 4 * NM / NPC) piece(std::integral_constant<int, 4>{});
+                    if (m == 5 * NM / NPC) piece(std::integral_constant<int, 5>{});
+                    if (m == 6 * NM / NPC) piece(std::integral_constant<int, 6>{});
+                    if (m == 7 * NM / NPC) piece(std::integral_constant<int, 7>{});
+                    if (m == 8 * NM / NPC) piece(std::integral_constant<int, 8>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        static_assert(NPC <= 9 && NPC <= NM, "more pieces than slots");
+        wait_vmcnt<LPT>();                       // k-step kt+2 landed (this wave's pieces); kt+3 stays in flight
+        if (PRO == 1) prologue_in_lds(slot(kt + 2));
+        __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0) -- the builtin, so that hipcc's wait-count pass knows the set is in
         __builtin_amdgcn_s_barrier();
-        if (++stage == NSTAGE) stage = 0;
+    };
+
+    issue(0, 0);
+    issue(1, 1);
+    issue(2, 2);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * LPT) : "memory");
+    if (PRO == 1) prologue_in_lds(0);
+    __builtin_amdgcn_s_barrier();
+    load_frags(0, fa0, fb0);
+    wait_vmcnt<LPT>();
+    if (PRO == 1) prologue_in_lds(1);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();                                // k-step 1 published, slot 0 read out
+    for (int kt = 0; kt < nk; kt += 2) {
+        kstep(kt, fa0, fb0, fa1, fb1);
+        if (kt + 1 < nk) kstep(kt + 1, fa1, fb1, fa0, fb0);
     }
+    wait_vmcnt<0>();                                             // the zero-fill pieces of the last k-steps: the epilogues reuse the ring
+    __builtin_amdgcn_s_barrier();
 
     // ================================== epilogues =====================================================
     // The ring is dead by now (every wave passed the last barrier after its last fragment read).  Nothing waits on the
