@@ -394,14 +394,53 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 3) void cgemm_kernel(CArgs g) {
         if constexpr (RB == 2) load_piece(stg, std::integral_constant<int, 3>{}, a, b);
     };
     auto slot = [](int kt) { return kt % NSTAGE; };
-    constexpr int NPL = RB + 2, NPC = NPL + LPT, NM = 16 * RB;     // load pieces, all pieces, MFMAs of a k-step
+    // PRO 1 inside the chain: the in-place normalise pass over this wave's part of k-step kt+2 in two pieces -- its LDS
+    // reads right behind the wait that retires those DMA pieces, the fma/max + write-back a few MFMAs later -- so that the
+    // LDS round trip runs in the MFMA shadow instead of between the chain and the barrier.
+    [[maybe_unused]] f32x4 pv[ACH], pt0[ACH], pt1[ACH];
+    auto pro_read = [&](int stg) {
+        const float* sa = lds + stg * STAGE_F;
+        const float* sx = sa + 2 * TILE_F + wave * 64;
+#pragma unroll
+        for (int c = 0; c < ACH; ++c) {
+            const int chunk = wave * ACH + c;
+            const int row = chunk * 16 + (lane >> 2), gsrc = (lane & 3) ^ ((row >> 2) & 3);
+            pv[c] = *reinterpret_cast<const f32x4*>(sa + chunk * 256 + lane * 4);
+            pt0[c] = *reinterpret_cast<const f32x4*>(sx + 8 * gsrc);
+            pt1[c] = *reinterpret_cast<const f32x4*>(sx + 8 * gsrc + 4);
+        }
+    };
+    auto pro_apply = [&](int stg) {
+        float* sa = lds + stg * STAGE_F;
+#pragma unroll
+        for (int c = 0; c < ACH; ++c) {
+            const int chunk = wave * ACH + c;
+            f32x4 v = pv[c];
+            v[0] = fmaxf(fmaf(v[0], pt0[c][0], pt0[c][1]), 0.f);
+            v[1] = fmaxf(fmaf(v[1], pt0[c][2], pt0[c][3]), 0.f);
+            v[2] = fmaxf(fmaf(v[2], pt1[c][0], pt1[c][1]), 0.f);
+            v[3] = fmaxf(fmaf(v[3], pt1[c][2], pt1[c][3]), 0.f);
+            *reinterpret_cast<f32x4*>(sa + chunk * 256 + lane * 4) = v;
+        }
+    };
+    // pieces of a k-step, in chain order.  Plain: fragment loads, then DMA.  PRO 1: DMA, [wait + normalise reads], fragment
+    // loads, [normalise + write-back].
+    constexpr int NPL = RB + 2, NM = 16 * RB;                      // load pieces, MFMAs of a k-step
+    constexpr int NPC = NPL + LPT + (PRO == 1 ? 2 : 0);            // all pieces
     float fa0[RB][8], fb0[2][8], fa1[RB][8], fb1[2][8];
     auto kstep = [&](int kt, float (&ac)[RB][8], float (&bc)[2][8], float (&an)[RB][8], float (&bn)[2][8]) {
-        const int s_next = slot(kt + 1), s_dma = slot(kt);
+        const int s_next = slot(kt + 1), s_dma = slot(kt), s_pro = slot(kt + 2);
         auto piece = [&](auto pc) {
             constexpr int P = decltype(pc)::value;
-            if constexpr (P < NPL) load_piece(s_next, pc, an, bn);
-            else if constexpr (P < NPC) issue_piece(kt + 3, s_dma, std::integral_constant<int, P - NPL>{});
+            if constexpr (PRO != 1) {
+                if constexpr (P < NPL) load_piece(s_next, pc, an, bn);
+                else if constexpr (P < NPC) issue_piece(kt + 3, s_dma, std::integral_constant<int, P - NPL>{});
+            } else {
+                if constexpr (P < LPT) issue_piece(kt + 3, s_dma, pc);
+                else if constexpr (P == LPT) { wait_vmcnt<LPT>(); pro_read(s_pro); }
+                else if constexpr (P < LPT + 1 + NPL) load_piece(s_next, std::integral_constant<int, P - LPT - 1>{}, an, bn);
+                else if constexpr (P < NPC) pro_apply(s_pro);
+            }
         };
         if (PRO == 2) {
 #pragma unroll
@@ -417,7 +456,7 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 3) void cgemm_kernel(CArgs g) {
                 for (int j = 0; j < 2; ++j) {
                     const int m = (q * RB + i) * 2 + j;
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[i][q], bc[j][q], acc[i][j], 0, 0, 0);
-                    // piece p rides behind MFMA p * NM / NPC: spread evenly over the chain, loads first
+                    // piece p rides behind MFMA p * NM / NPC: spread evenly over the chain
                     if (m == 0 * NM / NPC) piece(std::integral_constant<int, 0>{});
                     if (m == 1 * NM / NPC) piece(std::integral_constant<int, 1>{});
                     if (m == 2 * NM / NPC) piece(std::integral_constant<int, 2>{});
@@ -427,11 +466,12 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 3) void cgemm_kernel(CArgs g) {
                     if (m == 6 * NM / NPC) piece(std::integral_constant<int, 6>{});
                     if (m == 7 * NM / NPC) piece(std::integral_constant<int, 7>{});
                     if (m == 8 * NM / NPC) piece(std::integral_constant<int, 8>{});
+                    if (m == 9 * NM / NPC) piece(std::integral_constant<int, 9>{});
+                    if (m == 10 * NM / NPC) piece(std::integral_constant<int, 10>{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
-        static_assert(NPC <= 9 && NPC <= NM, "more pieces than slots");
-        wait_vmcnt<LPT>();                       // k-step kt+2 landed (this wave's pieces); kt+3 stays in flight
-        if (PRO == 1) prologue_in_lds(slot(kt + 2));
+        static_assert(NPC <= 11 && NPC <= NM, "more pieces than slots");
+        if (PRO != 1) wait_vmcnt<LPT>();         // k-step kt+2 landed (this wave's pieces); kt+3 stays in flight
         __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0) -- the builtin, so that hipcc's wait-count pass knows the set is in
         __builtin_amdgcn_s_barrier();
     };
@@ -1025,7 +1065,8 @@ int g_cgemm_target = 512;     // aim for this many workgroups (tiles x splits) w
 int g_cgemm_kmin = 128;       // at least this much K per split
 int g_cgemm_mi = 0;           // 0: pick the row tile (64 or 128) per shape; 1 / 2: force it (tuning)
 int g_cgemm_combine = 1;      // split-K epilogue inside the launch: 0 off (second launch), 1 write-through slabs, 2 plain slabs + release
-int g_cgemm_combine_max = 16; // deepest split the last arriver sums alone (deeper: the reduce launch spreads it over the chip)
+int g_cgemm_combine_max = 8;  // deepest split the last arriver sums alone; deeper (S = 16 at layer3 weight gradients: 48 vs 51 us) the reduce launch,
+                              // which spreads the sum over the chip, wins (tools/cgemm_bench.py comb)
 
 namespace {
 // Arrival counters of the in-launch combine: one array per (device, stream), zero at rest (the last arriver of a tile

@@ -856,9 +856,13 @@ def test_encoder_gradients_are_as_close_to_fp64_as_cpu_fp32_is(dev):
     run in fp64 on the CPU.  A randomly initialised 152-layer trunk in training mode (batch statistics) is badly
     conditioned: torch's OWN fp32 CPU gradients are ~1e-1 from fp64 (ReLU-mask flips compounded through ~150
     BatchNorm layers; measured 9.8e-2 over all fine-tuned parameters).  So fp64 is the anchor and CPU fp32 the
-    yardstick: per stage (layer2, layer3, layer4) and over all parameters the GPU's distance to fp64 must not exceed the
-    CPU fp32's by more than 25 % (measured: 9.66e-2 vs 9.76e-2 globally, medians within 5 %).  The block-level test
-    (test_fused_bottleneck_vs_fp64) holds single blocks to 1e-4; this one shows nothing is lost in composition.
+    yardstick: over all fine-tuned parameters the GPU's distance to fp64 must not exceed the CPU fp32's by more than 25 %
+    (measured 9.7e-2 vs 9.8e-2), per stage (layer2, layer3, layer4: medians of 75 / 327 / 30 tensors) by more than 50 %.
+    Both numbers are one draw each of a chaotic amplification of last-bit differences -- the per-stage ratio moved between
+    1.13 and 1.29 over three builds of this round whose kernels differ only in summation order -- so this test can only
+    show that NOTHING GROSS is lost in composition.  What pins the trunk's precision are the tests that remove the
+    chaos: tests/test_gpu_parity_r3.py::test_well_conditioned_trunk_gradients_vs_fp64 (mask-unambiguous construction, all
+    432 gradients <= 1e-3, median 3e-5) and the block-level test_fused_bottleneck_vs_fp64 (2e-4 at full size).
     Parity against the reference's torchvision stays unpinned."""
     import copy
     import statistics
@@ -900,7 +904,7 @@ def test_encoder_gradients_are_as_close_to_fp64_as_cpu_fp32_is(dev):
         ks = [k for k in g64 if k.startswith(stage)]
         mg, mc = statistics.median(eg[k] for k in ks), statistics.median(ec[k] for k in ks)
         lines.append("%s (%d tensors): median rel-l2 to fp64  gpu %.3e  cpu-fp32 %.3e" % (stage, len(ks), mg, mc))
-        assert mg <= 1.25 * mc + 1e-3, (stage, mg, mc)
+        assert mg <= 1.5 * mc + 1e-3, (stage, mg, mc)
     cat = lambda d: torch.cat([d[k].flatten().double() for k in g64])
     a64 = cat(g64)
     tg, tc = ((cat(gg) - a64).norm() / a64.norm()).item(), ((cat(g32) - a64).norm() / a64.norm()).item()
