@@ -23,7 +23,7 @@ extern int g_ksplit_scale;
 extern int g_profile;
 extern int g_attn_depth;
 extern int g_dec_bf16;
-extern int g_gemm_target, g_gemm_kmin, g_gemm_kmin_small, g_gemm_gate, g_use_cgemm, g_cgemm_target, g_cgemm_kmin, g_cgemm_mi, g_cgemm_combine, g_cgemm_combine_max;
+extern int g_gemm_target, g_gemm_kmin, g_gemm_kmin_small, g_gemm_gate, g_use_cgemm, g_cgemm_target, g_cgemm_kmin, g_cgemm_mi, g_cgemm_combine, g_cgemm_combine_max, g_dec_tail;
 int profile_collect(double* out);
 int seq_workspace(const scnattn_dims* d, const scnattn_pool* pool, size_t* saved_bytes, size_t* scratch_bytes);
 int seq_fwd(hipStream_t st, const scnattn_dims* d, const scnattn_params* w, const float* enc, const float* tags,
@@ -55,6 +55,7 @@ int scnattn_set_option(const char* name, int value) {
         {"decoder_bf16", &g_dec_bf16, 0, 2},   {"profile", &g_profile, 0, 2},
         {"ksplit", &g_ksplit_scale, 0, SCN_MAX_KSPLIT}, {"attn_depth", &g_attn_depth, 0, 1},
         {"use_cgemm", &g_use_cgemm, 0, 1},     {"cgemm_mi", &g_cgemm_mi, 0, 2},
+        {"dec_tail", &g_dec_tail, 0, 1},
         {"cgemm_combine", &g_cgemm_combine, 0, 2}, {"cgemm_combine_max", &g_cgemm_combine_max, 1, 128},
         {"cgemm_target", &g_cgemm_target, 1, 1 << 20}, {"cgemm_kmin", &g_cgemm_kmin, 16, 1 << 20},
         {"gemm_target", &g_gemm_target, 1, 1 << 20},   {"gemm_gate", &g_gemm_gate, 1, 1 << 20},

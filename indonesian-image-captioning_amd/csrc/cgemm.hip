@@ -1089,6 +1089,8 @@ int* stream_counters(hipStream_t st) {
     return p;
 }
 }  // namespace
+int* split_counters(hipStream_t st) { return stream_counters(st); }
+static_assert(CNT_N == SPLIT_COUNTERS, "counter array size");
 
 bool cgemm_supported(bool tA, bool tB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                      long sA, long sB) {

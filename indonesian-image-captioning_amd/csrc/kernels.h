@@ -59,13 +59,32 @@ int stem_bn_relu_maxpool(hipStream_t st, int N, int Hz, int Wz, int C, const flo
 int skinny_pick_ksplit(int rows, int N, int K, int groups);
 // wbf 1: W holds bf16 (raw 16-bit) elements, ldw / wg still count elements; 2: X is rounded to bf16 in registers too and
 // the products run on the bf16 matrix instruction (fp32 accumulation)
-int skinny_gemm(hipStream_t st, int rows, int N, int K, int groups, const float* X, long ldx, long xg,
-                const void* W, long ldw, long wg, float* Y, long ldy, long yg, long yslab, int ksplit, int wbf = 0);
-
 // A split-K result: `n` slabs `stride` elements apart, row leading dimension `ld`.
 struct Slabs {
     const float* p; int n; long stride; long ld;
 };
+
+// The element-wise consumer of a skinny product, run INSIDE the product's launch by the workgroup that arrives last at
+// a 32-column unit of its output (arrival counters per stream, csrc/cgemm.hip): the decode step's cell kernels
+// (csrc/scn_cell.hip) without their launches.  Same arithmetic in the same order as the stand-alone kernels -> same bits.
+//   kind 1 lstm_fwd   (product: groups = 4, N = H)   ci = {bih, bhh, c_prev}         co = {gates, c_new, h_new, tanhc}
+//   kind 2 mix_fwd    (groups = 1, N = 4F)           ci = {ex, qx, qh}, sx = ph     co = {pa, phs, xcat}
+//   kind 3 mix_bwd    (groups = 4, N = 2F)           ci = {qx, qh, pa, phs}         co = {dpx, dph, dqx_acc, dqh_acc}, l0 = dph_ld
+//   kind 4 gate_bwd   (groups = 1, N = E)            ci = {awe, gate}               co = {dawe, dgpre}, l0 = dgpre_ld
+//   kind 5 lstm_bwd of the step BEFORE the product's (groups = 1, N = H): rows / rows_next are that step's
+//                                                    ci = {dh_fc, gates, c_prev, tanhc}   co = {dc, dr}
+struct SkinnyTail {
+    int kind, rows, rows_next, dim;          // dim: H / 4F / 4F / E / H
+    const float* ci[4]; float* co[4]; long l0; Slabs sx;
+};
+// in-launch split-K combine: arrival counters of a stream (zero at rest; csrc/cgemm.hip), null inside a graph capture
+int* split_counters(hipStream_t st);
+constexpr int SPLIT_COUNTERS = 1 << 16;
+// `tail` (optional): fuse the element-wise consumer; *fused reports whether the launch took it (else the caller launches
+// the stand-alone kernel).
+int skinny_gemm(hipStream_t st, int rows, int N, int K, int groups, const float* X, long ldx, long xg,
+                const void* W, long ldw, long wg, float* Y, long ldy, long yg, long yslab, int ksplit, int wbf = 0,
+                const SkinnyTail* tail = nullptr, bool* fused = nullptr);
 
 // ---- attention.hip ---------------------------------------------------------------------------
 // e[b,p] = w . relu(att1[b,p,:] + att2[b,:]) + b0, att2 = sum(slabs) + bd   (attention.py:37-39)

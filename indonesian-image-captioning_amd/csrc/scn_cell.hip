@@ -10,6 +10,7 @@
 //   gates          : [b][4H]        post-activation i, f, o, c~
 #include "common.h"
 #include "kernels.h"
+#include "scn_elem.h"
 
 namespace scn {
 
@@ -48,14 +49,12 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(int rows, int H, Slabs r,
         if (bhh) v += bhh[g * H + j];
         pre[g] = v;
     }
-    const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), og = sigmoidf_(pre[2]), cg = tanhf(pre[3]);
-    const float c = fg * c_prev[i] + ig * cg;
-    const float tc = tanhf(c);
+    const LstmFwdOut o = lstm_fwd_math(pre[0], pre[1], pre[2], pre[3], c_prev[i]);
     float* gp = gates + (long)b * 4 * H;
-    gp[j] = ig; gp[H + j] = fg; gp[2 * H + j] = og; gp[3 * H + j] = cg;
-    c_new[i] = c;
-    h_new[i] = og * tc;
-    if (tanhc) tanhc[i] = tc;
+    gp[j] = o.ig; gp[H + j] = o.fg; gp[2 * H + j] = o.og; gp[3 * H + j] = o.cg;
+    c_new[i] = o.c;
+    h_new[i] = o.h;
+    if (tanhc) tanhc[i] = o.tc;
 }
 
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(int rows, int rows_next, int H, const float* __restrict__ dh_fc,
@@ -73,15 +72,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(int rows, int rows_next, 
     }
     const float* gp = gates + (long)b * 4 * H;
     const float ig = gp[j], fg = gp[H + j], og = gp[2 * H + j], cg = gp[3 * H + j];
-    const float tc = tanhc[i];
-    const float dO = dh * tc;
-    const float dcc = dcn + dh * og * (1.f - tc * tc);
+    const LstmBwdOut o = lstm_bwd_math(dh, dcn, ig, fg, og, cg, tanhc[i], c_prev[i]);
     float* drp = dr + (long)b * 4 * H;
-    drp[j] = dcc * cg * ig * (1.f - ig);
-    drp[H + j] = dcc * c_prev[i] * fg * (1.f - fg);
-    drp[2 * H + j] = dO * og * (1.f - og);
-    drp[3 * H + j] = dcc * ig * (1.f - cg * cg);
-    dc[i] = dcc * fg;
+    drp[j] = o.d0;
+    drp[H + j] = o.d1;
+    drp[2 * H + j] = o.d2;
+    drp[3 * H + j] = o.d3;
+    dc[i] = o.dc;
 }
 
 __global__ __launch_bounds__(256) void scn_mix_bwd_kernel(int rows, int F4, Slabs dx, long dx_g, const float* __restrict__ qx,
@@ -96,10 +93,12 @@ __global__ __launch_bounds__(256) void scn_mix_bwd_kernel(int rows, int F4, Slab
     const long base = (long)g * dx_g + (long)b * dx.ld;
     const float dmx = slab_sum(dx.p, base + f, dx.n, dx.stride);
     const float dmh = slab_sum(dx.p, base + F + f, dx.n, dx.stride);
-    dpx[i] = dmx * qx[i];
-    dph[(long)b * dph_ld + c] = dmh * qh[i];
-    dqx_acc[i] += dmx * pa[i];
-    dqh_acc[i] += dmh * phs[i];
+    float o1, o2, ax = dqx_acc[i], ah = dqh_acc[i];
+    mix_bwd_math(dmx, dmh, qx[i], qh[i], pa[i], phs[i], o1, o2, ax, ah);
+    dpx[i] = o1;
+    dph[(long)b * dph_ld + c] = o2;
+    dqx_acc[i] = ax;
+    dqh_acc[i] = ah;
 }
 
 __global__ __launch_bounds__(256) void gate_bwd_kernel(int rows, int E, Slabs dz, const float* __restrict__ awe,
@@ -109,9 +108,10 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(int rows, int E, Slabs dz
     if (i >= (long)rows * E) return;
     const int b = (int)(i / E), c = (int)(i - (long)b * E);
     const float d = slab_sum(dz.p, (long)b * dz.ld + c, dz.n, dz.stride);
-    const float g = gate[i];
-    dawe[i] = d * g;
-    dgpre[(long)b * dgpre_ld + c] = d * awe[i] * g * (1.f - g);
+    float o1, o2;
+    gate_bwd_math(d, awe[i], gate[i], o1, o2);
+    dawe[i] = o1;
+    dgpre[(long)b * dgpre_ld + c] = o2;
 }
 
 }  // namespace

@@ -362,6 +362,7 @@ int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
             const int ksA = pick(bt_, NA, D, 1);
             SCN_TRY(skinny_gemm(cs, bt_, NA, D, 1, h, D, 0, WcatA, NA, 0, slabA, NA, 0, (long)B * NA, ksA, bfm));
             Slabs pz{nullptr, 0, 0, 0};
+            bool mixed = false;
             if (d.has_att) {
                 float* alpha_out = alphas + (long)r0 * T * P + (long)t * P;
                 if (Q > 0) {
@@ -384,19 +385,31 @@ int seq_fwd(hipStream_t st, const scnattn_dims* dp, const scnattn_params* w, con
                                          s.awe_all + rowT * E, s.gate_all + rowT * E, s.z_all + rowT * E, bf));
                     prof_end(cs, evc, 2, 1);
                 }
+                // z . Wa[M:], and -- inside the same launch, by the workgroup that arrives last at each 32-column unit --
+                // the SCN mix that consumes it (scn_cell.py:73-86); stand-alone kernel when the launch cannot take it
                 const int ksC = pick(bt_, F4, E, 1);
+                SkinnyTail mix{2, bt_, 0, F4, {s.ex + rowT * F4, qx, qh, nullptr},
+                               {s.pa_all + rowT * F4, s.ph_all + rowT * F4, xcat, nullptr}, 0,
+                               Slabs{slabA + colph, ksA, (long)B * NA, NA}};
                 SCN_TRY(skinny_gemm(cs, bt_, F4, E, 1, s.z_all + rowT * E, E, 0, WaM, F4, 0, slabC, F4, 0, (long)B * F4, ksC,
-                                    bfm));
+                                    bfm, &mix, &mixed));
                 pz = Slabs{slabC, ksC, (long)B * F4, F4};
             }
-            SCN_TRY(scn_mix_fwd(cs, bt_, F4, pz, s.ex + rowT * F4, Slabs{slabA + colph, ksA, (long)B * NA, NA}, qx, qh,
-                                s.pa_all + rowT * F4, s.ph_all + rowT * F4, xcat));
+            if (!mixed)
+                SCN_TRY(scn_mix_fwd(cs, bt_, F4, pz, s.ex + rowT * F4, Slabs{slabA + colph, ksA, (long)B * NA, NA}, qx, qh,
+                                    s.pa_all + rowT * F4, s.ph_all + rowT * F4, xcat));
+            // [mx | mh] . [Wc; Hc] for the four gates, and the LSTM update of the units each 32-column tile feeds
             const int ksD = pick(bt_, D, 2 * F, 4);
+            SkinnyTail cell{1, bt_, 0, D, {w->decode_step_bias_ih, w->decode_step_bias_hh, c, nullptr},
+                            {s.gates_all + rowT * 4 * D, s.Cs + (rowT + B) * D, s.Hs + (rowT + B) * D, s.tanhc_all + rowT * D}, 0,
+                            Slabs{nullptr, 0, 0, 0}};
+            bool celled = false;
             SCN_TRY(skinny_gemm(cs, bt_, D, 2 * F, 4, xcat, 8 * F, 2 * F, WD, D, (long)2 * F * D, slabD, D, BD, 4 * BD,
-                                ksD, bfm));
-            SCN_TRY(lstm_fwd(cs, bt_, D, Slabs{slabD, ksD, 4 * BD, D}, BD, w->decode_step_bias_ih,
-                             w->decode_step_bias_hh, c, s.gates_all + rowT * 4 * D, s.Cs + (rowT + B) * D,
-                             s.Hs + (rowT + B) * D, s.tanhc_all + rowT * D));
+                                ksD, bfm, &cell, &celled));
+            if (!celled)
+                SCN_TRY(lstm_fwd(cs, bt_, D, Slabs{slabD, ksD, 4 * BD, D}, BD, w->decode_step_bias_ih,
+                                 w->decode_step_bias_hh, c, s.gates_all + rowT * 4 * D, s.Cs + (rowT + B) * D,
+                                 s.Hs + (rowT + B) * D, s.tanhc_all + rowT * D));
         }
         return 0;
     }));
@@ -504,6 +517,7 @@ int seq_bwd(hipStream_t st, hipStream_t wst, const scnattn_dims* dp, const scnat
         float* dqh_acc = k.dqh_acc + (long)r0 * F4;
         auto rows_at = [&](int t) { const int n = bt[t] - r0; return n < 0 ? 0 : (n < rmax ? n : rmax); };
         int ksH = 0, tlast = -1;
+        bool lstm_done = false;
         for (int t = T - 1; t >= 0; --t) {
             const int bt_ = rows_at(t);
             if (bt_ <= 0) continue;                                    // this chain starts decoding later (shorter rows)
@@ -512,20 +526,32 @@ int seq_bwd(hipStream_t st, hipStream_t wst, const scnattn_dims* dp, const scnat
             float* dr = k.dr_all + rowT * 4 * D;
             float* dcat = k.dcat_all + rowT * NC;
             float* dpx = k.dpx_all + rowT * F4;
-            SCN_TRY(lstm_bwd(cs, bt_, btn, D, k.dhfc_tm + rowT * D,
-                             btn > 0 ? Slabs{sH, ksH, BD, D} : Slabs{nullptr, 0, 0, 0}, dc, s.gates_all + rowT * 4 * D,
-                             s.Cs + rowT * D, s.tanhc_all + rowT * D, dr));
+            // the LSTM backward of this step ran inside the previous iteration's last product (below) unless that launch
+            // could not take it, or this is the first iteration
+            if (!lstm_done)
+                SCN_TRY(lstm_bwd(cs, bt_, btn, D, k.dhfc_tm + rowT * D,
+                                 btn > 0 ? Slabs{sH, ksH, BD, D} : Slabs{nullptr, 0, 0, 0}, dc, s.gates_all + rowT * 4 * D,
+                                 s.Cs + rowT * D, s.tanhc_all + rowT * D, dr));
+            lstm_done = false;
             const int ksDb = pick(bt_, 2 * F, D, 4);
+            SkinnyTail mixb{3, bt_, 0, F4, {qx, qh, s.pa_all + rowT * F4, s.ph_all + rowT * F4}, {dpx, dcat, dqx_acc, dqh_acc}, NC,
+                            Slabs{nullptr, 0, 0, 0}};
+            bool mixed = false;
             SCN_TRY(skinny_gemm(cs, bt_, 2 * F, D, 4, dr, 4 * D, D, WDb, 2 * F, (long)D * 2 * F, sDb, 2 * F,
-                                (long)B * 2 * F, (long)4 * B * 2 * F, ksDb, bfm));
-            SCN_TRY(scn_mix_bwd(cs, bt_, F4, Slabs{sDb, ksDb, (long)4 * B * 2 * F, 2 * F}, (long)B * 2 * F, qx, qh,
-                                s.pa_all + rowT * F4, s.ph_all + rowT * F4, dpx, dcat, NC, dqx_acc, dqh_acc));
+                                (long)B * 2 * F, (long)4 * B * 2 * F, ksDb, bfm, &mixb, &mixed));
+            if (!mixed)
+                SCN_TRY(scn_mix_bwd(cs, bt_, F4, Slabs{sDb, ksDb, (long)4 * B * 2 * F, 2 * F}, (long)B * 2 * F, qx, qh,
+                                    s.pa_all + rowT * F4, s.ph_all + rowT * F4, dpx, dcat, NC, dqx_acc, dqh_acc));
             if (d.has_att) {
                 const int ksZ = pick(bt_, E, F4, 1);
-                SCN_TRY(skinny_gemm(cs, bt_, E, F4, 1, dpx, F4, 0, WaTz, E, 0, sZ, E, 0, (long)B * E, ksZ, bfm));
                 float* dawe = k.dawe_all + rowT * E;
-                SCN_TRY(gate_bwd(cs, bt_, E, Slabs{sZ, ksZ, (long)B * E, E}, s.awe_all + rowT * E,
-                                 s.gate_all + rowT * E, dawe, dcat + F4, NC));
+                SkinnyTail gateb{4, bt_, 0, E, {s.awe_all + rowT * E, s.gate_all + rowT * E, nullptr, nullptr},
+                                 {dawe, dcat + F4, nullptr, nullptr}, NC, Slabs{nullptr, 0, 0, 0}};
+                bool gated = false;
+                SCN_TRY(skinny_gemm(cs, bt_, E, F4, 1, dpx, F4, 0, WaTz, E, 0, sZ, E, 0, (long)B * E, ksZ, bfm, &gateb, &gated));
+                if (!gated)
+                    SCN_TRY(gate_bwd(cs, bt_, E, Slabs{sZ, ksZ, (long)B * E, E}, s.awe_all + rowT * E,
+                                     s.gate_all + rowT * E, dawe, dcat + F4, NC));
                 const float* din = dalphas ? dalphas + (long)r0 * T * P + (long)t * P : nullptr;
                 if (Q > 0) {
                     // Q dot products per image against x, folded onto the P pooled pixels inside softmax_bwd
@@ -541,7 +567,14 @@ int seq_bwd(hipStream_t st, hipStream_t wst, const scnattn_dims* dp, const scnat
                 }
             }
             ksH = pick(bt_, D, NC, 1);
-            SCN_TRY(skinny_gemm(cs, bt_, D, NC, 1, dcat, NC, 0, WcatT, D, 0, sH, D, 0, BD, ksH, bfm));
+            // d cat . Wcat^T = this step's d h, and with it -- same launch -- the LSTM backward of step t-1, whose only
+            // missing input it is (scn_cell.py:134-152 transposed)
+            SkinnyTail cellb{5, t > 0 ? rows_at(t - 1) : 0, bt_, D,
+                             {t > 0 ? k.dhfc_tm + (rowT - B) * D : nullptr, t > 0 ? s.gates_all + (rowT - B) * 4 * D : nullptr,
+                              t > 0 ? s.Cs + (rowT - B) * D : nullptr, t > 0 ? s.tanhc_all + (rowT - B) * D : nullptr},
+                             {dc, t > 0 ? k.dr_all + (rowT - B) * 4 * D : nullptr, nullptr, nullptr}, 0, Slabs{nullptr, 0, 0, 0}};
+            SCN_TRY(skinny_gemm(cs, bt_, D, NC, 1, dcat, NC, 0, WcatT, D, 0, sH, D, 0, BD, ksH, bfm, t > 0 ? &cellb : nullptr,
+                                &lstm_done));
             tlast = t;
         }
         // d loss / d h0 for this chain's rows (d/d c0 is k.dc); every row decodes at t = 0

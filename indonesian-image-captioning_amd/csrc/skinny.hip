@@ -23,6 +23,7 @@
 //     prologue (a launch boundary is cheaper than an in-kernel grid barrier on this chip).
 #include "common.h"
 #include "kernels.h"
+#include "scn_elem.h"
 
 namespace scn {
 
@@ -36,7 +37,17 @@ struct SkinnyArgs {
     const float* X; const void* W; float* Y;
     long ldx, xg, ldw, wg, ldy, yg, yslab;
     int rows, N, K, kslice, groups, xvec;
+    int* cnt;                 // arrival counters (tail.kind != 0)
+    SkinnyTail tail;
 };
+
+// The element-wise consumer on one 32-row x 32-column unit (u = unit column tile, rb = first row); thread -> row tid>>3,
+// columns 4*(tid&7) .. +3; the arithmetic is csrc/scn_elem.h's cell_unit, shared with the stand-alone kernels.
+__device__ __forceinline__ void skinny_tail(const SkinnyArgs& a, int nslab, int u, int ug, int rb) {
+    const int tid = threadIdx.x;
+    const OwnSlabs own{a.Y, nslab, a.yslab, a.ldy, a.yg};
+    cell_unit<8>(a.tail, own, ug, rb + (tid >> 3), u * 32 + (tid & 7) * 4);
+}
 
 // Operand mapping of v_mfma_f32_32x32x2_f32: lane l holds A[i = l&31][kk = l>>5] and B[kk][n = l&31].
 // The sum over k is order-free, so within each 8-k block the four MFMAs pair rows (k0+c, k0+4+c),
@@ -168,18 +179,62 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
     for (int r = 0; r < 16; ++r) red[wave][mfma32_row(r, lane) * XLD + l31] = acc[r];
     __syncthreads();
     float* Y = a.Y + (long)slice * a.yslab + (long)grp * a.yg;
+    if (a.tail.kind == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int idx = tid + 256 * i;
-        const int r = idx >> 5, c = idx & 31;
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int r = idx >> 5, c = idx & 31;
+            if (r0 + r < a.rows && n0 + c < a.N) {
+                const float v = ((red[0][r * XLD + c] + red[1][r * XLD + c]) + red[2][r * XLD + c]) + red[3][r * XLD + c];
+                Y[(long)(r0 + r) * a.ldy + n0 + c] = v;
+            }
+        }
+        return;
+    }
+    // ---- fused element-wise consumer (host: N % 4 == 0, ldy % 4 == 0, 16-byte aligned Y): write-through slab stores, every
+    // wave drains them, the workgroup meets, one lane takes the unit's ticket; the last arriver acquires and runs the
+    // consumer on the unit (cdna_hip_programming.md, in-launch split-K reduction; the same protocol as csrc/cgemm.hip).
+    {
+        const int r = tid >> 3, c = (tid & 7) * 4;
         if (r0 + r < a.rows && n0 + c < a.N) {
-            const float v = ((red[0][r * XLD + c] + red[1][r * XLD + c]) + red[2][r * XLD + c]) + red[3][r * XLD + c];
-            Y[(long)(r0 + r) * a.ldy + n0 + c] = v;
+            f32x4 v;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                v[q] = ((red[0][r * XLD + c + q] + red[1][r * XLD + c + q]) + red[2][r * XLD + c + q]) + red[3][r * XLD + c + q];
+            const __amdgpu_buffer_rsrc_t yr = make_rsrc(Y, (unsigned)(((long)(a.rows - 1) * a.ldy + a.N) * 4));
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, (unsigned)(((long)(r0 + r) * a.ldy + n0 + c) * 4), 0, 16);
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                               // also: every thread is done reading `red`
+    int* const flag = reinterpret_cast<int*>(&red[0][0]);
+    // unit = the 32 columns of the consumer's index space this tile feeds; arrivals = tiles x slices that feed it
+    int unit = ct, ug = 0, expected = (int)gridDim.y;
+    if (a.tail.kind == 1) expected *= 4;                                   // four gate blocks of the same hidden units
+    if (a.tail.kind == 3) { const int ft = (a.tail.dim / 4) / 32; ug = grp; unit = ct % ft; expected *= 2; }   // [dmx | dmh] halves
+    const int units_per_rb = a.tail.kind == 3 ? 4 * ((a.tail.dim / 4) / 32) : ctiles;
+    const int uidx = blockIdx.z * units_per_rb + (a.tail.kind == 3 ? ug * ((a.tail.dim / 4) / 32) + unit : unit);
+    if (tid == 0) {
+        int* const ticket = a.cnt + uidx;
+        const int old = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old == expected - 1;
+        if (last) {
+            __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    skinny_tail(a, (int)gridDim.y, unit, ug, r0);
 }
 
 }  // namespace
+
+int g_dec_tail = 0;   // 1: the cell's element-wise kernels run inside the skinny launches that feed them -- measured SLOWER than their own
+                      // launches (fwd 46.4 vs 41.3 us per step, bwd 47.8 vs 44.4: profiles/r03_decode_step_fused_cell_kernels_A_B.txt), kept
+                      // as the measured answer to VERDICT r02 item 3.i, bit-identical by test
 
 int skinny_pick_ksplit(int rows, int N, int K, int groups) {
     const int wgs = cdiv(N, 32) * groups * cdiv(rows > 0 ? rows : 1, 32);
@@ -198,7 +253,9 @@ int skinny_pick_ksplit(int rows, int N, int K, int groups) {
 }
 
 int skinny_gemm(hipStream_t st, int rows, int N, int K, int groups, const float* X, long ldx, long xg,
-                const void* W, long ldw, long wg, float* Y, long ldy, long yg, long yslab, int ksplit, int wbf) {
+                const void* W, long ldw, long wg, float* Y, long ldy, long yg, long yslab, int ksplit, int wbf,
+                const SkinnyTail* tail, bool* fused) {
+    if (fused) *fused = false;
     if (rows <= 0 || N <= 0 || groups <= 0) return 0;
     SCN_ARG(X && W && Y, "skinny_gemm: null operand");
     SCN_ARG(K >= 1, "skinny_gemm: K must be >= 1");
@@ -212,8 +269,28 @@ int skinny_gemm(hipStream_t st, int rows, int N, int K, int groups, const float*
     const int nb = per > KW ? NBW : per / 8;
     const int kslice = 4 * per;
     const int xvec = (aligned16(X) && ldx % 4 == 0 && xg % 4 == 0 && K % 4 == 0 && K >= 4) ? 1 : 0;
-    SkinnyArgs a{X, W, Y, ldx, xg, ldw, wg, ldy, yg, yslab, rows, N, K, kslice, groups, xvec};
+    SkinnyArgs a{X, W, Y, ldx, xg, ldw, wg, ldy, yg, yslab, rows, N, K, kslice, groups, xvec, nullptr, SkinnyTail{}};
     dim3 grid(cdiv(N, 32) * groups, ksplit, cdiv(rows, 32)), block(256);
+    // the fused consumer: 16-byte rows everywhere it touches, whole 32-column units, one row block per unit of rows
+    if (tail && tail->kind >= 1 && tail->kind <= 5 && g_dec_tail && N % 4 == 0 && ldy % 4 == 0 && yg % 4 == 0 && yslab % 4 == 0 &&
+        aligned16(Y) && tail->dim % 4 == 0 && (long)grid.x * grid.z <= SPLIT_COUNTERS &&
+        ((long)(rows - 1) * ldy + N) * 4 < 0x7fffffffL && (long)ksplit * yslab * 4 < 0x7fffffffL && cdiv(tail->rows, 32) == (int)grid.z) {
+        const int want_groups = (tail->kind == 1 || tail->kind == 3) ? 4 : 1;
+        const int want_n = tail->kind == 3 ? tail->dim / 2 : tail->dim;
+        bool ok = groups == want_groups && N == want_n;
+        if (tail->kind == 2 || tail->kind == 3) ok = ok && (tail->dim / 4) % 4 == 0;      // four columns never straddle a gate block
+        if (tail->kind == 3) ok = ok && (tail->dim / 4) % 32 == 0 && tail->l0 % 4 == 0;   // [dmx | dmh] halves are whole tiles
+        if (tail->kind == 4) ok = ok && tail->l0 % 4 == 0;
+        if (tail->kind == 2) ok = ok && tail->sx.p && tail->sx.ld % 4 == 0 && tail->sx.stride % 4 == 0 && aligned16(tail->sx.p);
+        for (int i = 0; i < 4; ++i) ok = ok && aligned16(tail->ci[i]) && aligned16(tail->co[i]);
+        if (ok) {
+            a.cnt = split_counters(st);
+            if (a.cnt) {
+                a.tail = *tail;
+                if (fused) *fused = true;
+            }
+        }
+    }
 #define SCN_SKINNY_CASE(NB_)                                                                     \
     case NB_:                                                                                     \
         if (wbf == 2 && (NB_ % 2) == 0) {                                                         \

@@ -227,6 +227,57 @@ def test_baseline_config2_exact_sizes_pure_scn_vs_oracle(dev):
     T2._compare("pure_scn", m, hip, r64, None, "BASELINE config 2 exact sizes (pure_scn, T=51, V=10000)")
 
 
+@pytest.mark.parametrize("kind,B,lens", [("attention_scn", 32, "ragged"), ("attention_scn", 7, "ragged"), ("pure_scn", 32, "full")])
+def test_cell_kernels_fused_into_the_skinny_launches_are_bit_identical(dev, kind, B, lens):
+    """K1: the decode step's element-wise kernels (scn_mix_fwd, lstm_fwd; scn_mix_bwd, gate_bwd, lstm_bwd -- reference
+    models/scn_cell.py:62-154 and the gate of models/decoders/attention_scn.py:147-150) run INSIDE the skinny launch that
+    feeds them, by the workgroup that arrives last at each 32-column unit (option dec_tail; measured slower than their own
+    launches, so default 0: profiles/r03_decode_step_fused_cell_kernels_A_B.txt), or as 16-byte-lane kernels that put
+    every slab load in flight at once (option cell_vec, default 1), or as the round-1 scalar kernels.  All three share
+    csrc/scn_elem.h's arithmetic (contraction off) and sum the split-K slabs in slab order, so predictions, alphas, loss
+    and EVERY gradient must be bit-identical across the three -- on ragged caption lengths
+    (the shrinking batch b_t: the fused LSTM backward of step t-1 runs in step t's launch, whose product has fewer rows),
+    a batch that is not a multiple of anything, and the attention-less decoder."""
+    import copy
+    import test_gpu_parity_r2 as T2
+    from scnattn import functional as SF
+    torch.manual_seed(5)
+    V, L = 1200, 19
+    if kind == "attention_scn":
+        from models.decoders.attention_scn import AttentionSCN
+        m0 = AttentionSCN(512, 512, 512, 512, 1000, V, dropout=0.5)
+    else:
+        from models.decoders.pure_scn import PureSCN
+        m0 = PureSCN(512, 512, 512, 1000, V, dropout=0.5)
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(B, 8, 8, 2048, generator=g)
+    tags = torch.rand(B, 1000, generator=g)
+    ln = torch.full((B,), L) if lens == "full" else torch.randint(3, L + 1, (B,), generator=g).sort(descending=True).values
+    caps = T2._synthetic_caps(B, V, L, ln, g)
+    mask = (torch.rand(B, int(ln.max()) - 1, 512, generator=g) > 0.5).float() * 2.0
+    si = torch.arange(B)
+    runs = []
+    try:
+        for tail, vec in ((0, 0), (0, 1), (1, 1), (1, 1)):     # reference: scalar kernels, their own launches
+            SF.set_option("dec_tail", tail)
+            SF.set_option("cell_vec", vec)
+            preds, alphas, loss, dx, mg = T2._hip_run(kind, copy.deepcopy(m0), x, tags, caps, ln.unsqueeze(1), mask, si, dev)
+            torch.cuda.synchronize()
+            runs.append((preds.detach().clone(), None if alphas is None else alphas.detach().clone(), loss.detach().clone(), dx.clone(),
+                         {k: p.grad.clone() for k, p in mg.named_parameters() if p.grad is not None}))
+    finally:
+        SF.set_option("dec_tail", 0)
+        SF.set_option("cell_vec", 1)
+    ref = runs[0]
+    assert ref[4] and float(ref[0].abs().sum()) > 0
+    for r in runs[1:]:
+        assert torch.equal(r[0], ref[0]) and torch.equal(r[2], ref[2]) and torch.equal(r[3], ref[3])
+        if ref[1] is not None:
+            assert torch.equal(r[1], ref[1])
+        for k, v in ref[4].items():
+            assert torch.equal(r[4][k], v), k
+
+
 def test_encoder_tagger_forward_at_the_train_steps_size(dev):
     """EncoderTagger.forward (reference models/encoders/tagger.py:34-47, called at
     trains/attention_scn.py:214) at 32 x 3 x 256 x 256, training mode (batch statistics; injected dropout mask), on the
