@@ -232,10 +232,9 @@ def test_cell_kernels_fused_into_the_skinny_launches_are_bit_identical(dev, kind
     """K1: the decode step's element-wise kernels (scn_mix_fwd, lstm_fwd; scn_mix_bwd, gate_bwd, lstm_bwd -- reference
     models/scn_cell.py:62-154 and the gate of models/decoders/attention_scn.py:147-150) run INSIDE the skinny launch that
     feeds them, by the workgroup that arrives last at each 32-column unit (option dec_tail; measured slower than their own
-    launches, so default 0: profiles/r03_decode_step_fused_cell_kernels_A_B.txt), or as 16-byte-lane kernels that put
-    every slab load in flight at once (option cell_vec, default 1), or as the round-1 scalar kernels.  All three share
-    csrc/scn_elem.h's arithmetic (contraction off) and sum the split-K slabs in slab order, so predictions, alphas, loss
-    and EVERY gradient must be bit-identical across the three -- on ragged caption lengths
+    launches, so default 0: profiles/r03_decode_step_fused_cell_kernels_A_B.txt).  Both paths share csrc/scn_elem.h's
+    arithmetic (contraction off) and sum the split-K slabs in slab order, so predictions, alphas, loss and EVERY
+    gradient must be bit-identical -- on ragged caption lengths
     (the shrinking batch b_t: the fused LSTM backward of step t-1 runs in step t's launch, whose product has fewer rows),
     a batch that is not a multiple of anything, and the attention-less decoder."""
     import copy
@@ -258,16 +257,14 @@ def test_cell_kernels_fused_into_the_skinny_launches_are_bit_identical(dev, kind
     si = torch.arange(B)
     runs = []
     try:
-        for tail, vec in ((0, 0), (0, 1), (1, 1), (1, 1)):     # reference: scalar kernels, their own launches
+        for tail in (0, 1, 1):     # reference: their own launches
             SF.set_option("dec_tail", tail)
-            SF.set_option("cell_vec", vec)
             preds, alphas, loss, dx, mg = T2._hip_run(kind, copy.deepcopy(m0), x, tags, caps, ln.unsqueeze(1), mask, si, dev)
             torch.cuda.synchronize()
             runs.append((preds.detach().clone(), None if alphas is None else alphas.detach().clone(), loss.detach().clone(), dx.clone(),
                          {k: p.grad.clone() for k, p in mg.named_parameters() if p.grad is not None}))
     finally:
         SF.set_option("dec_tail", 0)
-        SF.set_option("cell_vec", 1)
     ref = runs[0]
     assert ref[4] and float(ref[0].abs().sum()) > 0
     for r in runs[1:]:
