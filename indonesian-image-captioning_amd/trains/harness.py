@@ -7,6 +7,8 @@ One call of ``TrainStep.step()`` =
     -> zero_grad -> backward (+ bucketed RCCL all-reduce when world > 1) -> clamp +-5 -> Adam.
 Data loading and the ``.item()`` metric syncs of the reference are outside the step.
 Tags are a synthetic input (the tagger encoder is a "next" row of SURVEY.md 8f)."""
+import os
+
 import torch
 from torch import nn
 from torch.nn.utils.rnn import pack_padded_sequence
@@ -55,6 +57,9 @@ def build_decoder(kind, cfg):
         return PureAttention(cfg["attention_dim"], cfg["emb_dim"], cfg["decoder_dim"], cfg["vocab_size"],
                              dropout=cfg["dropout"])
     raise ValueError("Error model type not found!")
+
+
+_DIAG_SLEEP_CYCLES = int(os.environ.get("SCNATTN_DIAG_BWD_HEADSTART_CYCLES", "0"))
 
 
 class TrainStep:
@@ -208,6 +213,8 @@ class TrainStep:
             self.encoder_optimizer.zero_grad()
         for r in self.reducers:
             r.reset()
+        if _DIAG_SLEEP_CYCLES:      # diagnostics (tools/README.md): keep the GPU busy so that the host enqueues backward() ahead of it
+            torch.cuda._sleep(_DIAG_SLEEP_CYCLES)
         loss.backward()
         if ev is not None:
             from scnattn import conv as _conv
