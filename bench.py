@@ -322,9 +322,9 @@ def main():
 
     last_loss = [None]
     # --host-lengths (experiment): hand the decoder the caption lengths as a CPU tensor too, so that its forward pass
-    # needs no device synchronisation to learn its loop bounds.  Measured SLOWER (785-790 vs 805-807 images/s): the one
-    # sync per step (the reference's own `.tolist()`, attention_scn.py:131) keeps the host from running so far ahead
-    # that blocks the side stream still holds cannot be reused and the caching allocator has to hipMalloc.
+    # needs no device synchronisation to learn its loop bounds.  Round 3, after a long warm-up: 815 vs 812 images/s with
+    # 18.8 instead of 10.4 GiB reserved (the host runs a step ahead, so blocks the side stream still holds cannot be
+    # reused); with the default warm-up the extra hipMallocs make it slower.  Not worth a second copy of the activations.
     caplens_host = caplens.cpu() if (args.host_lengths and batches is None) else None
 
     step_marks = []      # one HIP event per step end (no synchronisation): per-step durations -> the median of SURVEY 8(d)
@@ -499,7 +499,7 @@ def main():
             dbf = args.decoder_dtype in ("bf16", "bf16mfma")
             pmc_name = ("r02_pmc_decode_step_fwd_%s_bf16mfma.json" if args.decoder_dtype == "bf16mfma" else
                         "r02_pmc_decode_step_fwd_%s_bf16.json" if dbf else
-                        "r02_pmc_decode_step_fwd_%s.json" if pooled else "r01_pmc_decode_step_fwd_%s.json") \
+                        "r03_pmc_decode_step_fwd_%s.json" if pooled else "r01_pmc_decode_step_fwd_%s.json") \
                 % ("pooled" if pooled else "dense")
             pmc = os.path.join(ROOT, "profiles", pmc_name)
             if args.batch == 32 and os.path.exists(pmc):   # PMC passes cannot run inside this process;
@@ -562,7 +562,7 @@ def main():
                         "encoder's forward + backward time (HIP events on the launch stream around encoder(imgs) and from the "
                         "moment the decoder's backward pass hands over d(feature map) to the end of backward(), side-stream "
                         "weight gradients joined; median of 3 extra steps outside the timed region); peak = %s matrix peak at "
-                        "2.4 GHz -- the chip sustains ~2.0 GHz under this load (131 TFLOP/s at 4096^3 = 100 %% matrix-pipe busy)"
+                        "2.4 GHz -- the chip sustains ~2.0 GHz under this load (csrc/cgemm.hip: 131-134 TFLOP/s at 4096^3)"
                         % ("fine-tuning layer2-4" if fine_tune else "frozen (forward only)",
                            ENC_GFLOP_PER_IMAGE[bool(fine_tune)], args.batch, "bf16" if bf else "fp32-input")}
         if world == 1 and not args.no_cpu_baseline and not args.decoder_only:
