@@ -23,7 +23,9 @@
 extern "C" {
 #endif
 
-#define SCNATTN_VERSION 107 /* 0.1.7: + halo-staged 3x3 weight gradient, strided 3x3 d input, the stem (scnattn_stem_*), BatchNorm
+#define SCNATTN_VERSION 108 /* 0.1.8: + bf16 trunk kernels (scnattn_cgemm16, _conv3x3_fwd16/_dgrad16, _wgrad16_*, _bf16_weights), split-K
+                               epilogues inside the GEMM launch (options cgemm_combine, cgemm_combine_max), option dec_tail;
+                               0.1.7: + halo-staged 3x3 weight gradient, strided 3x3 d input, the stem (scnattn_stem_*), BatchNorm
                                finalize on load; - whole-block drivers, scnattn_stream_*, the experiment options of rounds 1-2 */
 
 int scnattn_version(void);
@@ -38,7 +40,11 @@ const char* scnattn_last_error(void);
  *     skinny GEMMs; 0 = auto), "attn_depth", "use_cgemm" (0: every dense product on the round-1 sgemm kernel), "cgemm_mi"
  *     (0 auto; 1 / 2 force the 64- / 128-row tile), "cgemm_target" (workgroups a split-K product aims for, 512),
  *     "cgemm_kmin" (smallest K per slab, 128), "gemm_target" / "gemm_gate" / "gemm_kmin" / "gemm_kmin_small" (the same for
- *     sgemm).  The experiment switches of rounds 1-2 (fuse_attn, chains, attn_handoff, cgemm_stagger, cgemm_w41, cgemm_vec,
+ *     sgemm), "cgemm_combine" (1, default: a split product's epilogue is run inside the launch by the workgroup that arrives
+ *     last at each tile -- write-through slabs, arrival counters per stream, bit-identical to the reduce launch; 2: plain
+ *     slab stores + an agent release; 0: always the reduce launch), "cgemm_combine_max" (deepest split combined in-launch, 8),
+ *     "dec_tail" (0, default; 1: the decode step's element-wise cell kernels run inside the skinny launches that feed
+ *     them -- bit-identical, measured slower: DESIGN.md 6c).  The experiment switches of rounds 1-2 (fuse_attn, chains, attn_handoff, cgemm_stagger, cgemm_w41, cgemm_vec,
  *     bn_gfirst, skinny_tail) were removed together with the code paths they selected; DESIGN.md keeps their numbers.
  * Returns -1 for an unknown name or an out-of-range value. */
 int scnattn_set_option(const char* name, int value);

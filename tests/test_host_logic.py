@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(h, name), "libscnattn.so does not export " + name
     assert set(L.EXPORTS) <= declared | {"scnattn_last_error"}
-    assert h.scnattn_version() == 107
+    assert h.scnattn_version() == 108
 
 
 def test_invalid_arguments_return_codes_and_messages():
