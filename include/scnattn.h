@@ -424,6 +424,36 @@ int scnattn_wgrad16_3x3(void* stream, int N, int H, int W, int Cin, int Cout, co
 int scnattn_wgrad16_rows(void* stream, int R, int Cin, int Cout, const void* dy, const void* x, long src_rows, float* dw,
                          long ldo, int gs, int gHi, int gWi, int gHo, int gWo, int goh, int gow, float* ws, long ws_floats,
                          int k_slices);
+/* ---- one mixed-precision Bottleneck from ONE call per direction (csrc/block16.cpp) -------------------------------------------
+ * torchvision's Bottleneck.forward (conv1-bn1-relu-conv2-bn2-relu-conv3-bn3 [+ downsample] + identity, relu; the blocks of the
+ * trunk built at models/encoders/caption.py:17-22) and its gradient as the launch sequences above, enqueued by the library:
+ * the bf16 step is bound by what the HOST spends per launch (~25 calls per block and direction from Python), not by the GPU.
+ * The library still allocates nothing: the caller sizes three buffers with scnattn_block16_sizes and owns them.
+ *   save  (bf16): z1 a1 | z2 a2 | z3 out | [zd idn]   -- everything the backward pass re-reads; `out` (the block's result,
+ *                 [N*Ho*Wo][4p]) starts at out_offset elements;
+ *   stats (fp32): [4][2][4p]  mean, invstd of bn1, bn2, bn3, downsample.1 (written by the forward call);
+ *   tmp   (bf16, backward): dres dz3 | dz2 | dz1 | [dzd dx dxd];  dgb (fp32, backward): [4][2][4p]  d beta, d gamma.
+ * BatchNorm index: 0 bn1, 1 bn2, 2 bn3, 3 downsample.1; convolution index: 0 conv1, 1 conv2, 2 conv3, 3 downsample.0.
+ * shift[i]: conditioning shift of BatchNorm i (scnattn_bn_apply_fin); w / wt: the bf16 copies of scnattn_bf16_weights.
+ * Backward: weight gradients with a non-null dw[i] are written there (fp32, the parameter's layout); with side_stream they run
+ * on it, forked from `stream` by events (the caller joins it and keeps save / tmp / x alive until then).  dx_out receives the
+ * gradient of the block input: for an identity block it is dres (accumulated in place); with a downsample the caller adds
+ * dxd_out (the [N*Ho*Wo][Cin] gradient through downsample.0) into the strided rows of dx_out itself. */
+typedef struct scnattn_block16 {
+    int N, Cin, Hi, Wi, p, stride, has_down, pad;
+    const float* gamma[4]; const float* beta[4]; float* run_mean[4]; float* run_var[4]; const float* shift[4];
+    float eps[4], momentum[4];
+    const void* w[4]; const void* wt[4];
+    float* ws; long ws_floats; float* part; float* bnpart; long bnpart_floats;
+    const void* x; void* save; float* stats;
+    /* backward only */
+    const void* dout; void* tmp; float* dgb; float* dw[4]; int need_dx, pad2;
+    void* side_stream; float* side_ws; long side_ws_floats;
+} scnattn_block16;
+int scnattn_block16_sizes(const scnattn_block16* b, long* save_elems, long* out_offset, long* stats_floats, long* tmp_elems,
+                          long* dgb_floats);
+int scnattn_block16_fwd(void* stream, const scnattn_block16* b);
+int scnattn_block16_bwd(void* stream, const scnattn_block16* b, void** dx_out, void** dxd_out);
 /* scnattn_bn_stats (fp32 maps) that also writes the folded {scale, shift} pairs [C][2] for a consumer's prologue */
 int scnattn_bn_stats_fold(void* stream, int R, int C, const void* x, float eps, float momentum, float* partial,
                           float* mean, float* invstd, float* run_mean, float* run_var, const float* gamma,

@@ -87,6 +87,9 @@ _SIGS = {
     "scnattn_conv3x3_fwd16": ([vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, C.POINTER(ConvExtra), vp, i64], i32),
     "scnattn_conv3x3_dgrad16": ([vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i64], i32),
     "scnattn_wgrad16_3x3": ([vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i64, i32], i32),
+    "scnattn_block16_sizes": ([vp, vp, vp, vp, vp, vp], i32),
+    "scnattn_block16_fwd": ([vp, vp], i32),
+    "scnattn_block16_bwd": ([vp, vp, vp, vp], i32),
     "scnattn_wgrad16_rows": ([vp, i32, i32, i32, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp, i64, i32], i32),
     "scnattn_stem_tiles": ([i32, i32, i32], i32),
     "scnattn_stem_conv7": ([vp, i32, i32, i32, vp, i64, i64, i64, i64, vp, i64, i64, i64, i64, vp, vp, vp], i32),

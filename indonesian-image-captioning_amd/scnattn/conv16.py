@@ -16,6 +16,7 @@ but every feature map and every gradient map is bf16 in HBM and every convolutio
 `Bottleneck.forward` (scnattn/resnet.py) calls `bottleneck()` when its input is a bf16 CUDA map in training mode; the
 trunk produces one when it runs under `torch.autocast("cuda", dtype=torch.bfloat16)` (scnattn/stem.py)."""
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -261,6 +262,143 @@ class _Bottleneck16Fn(torch.autograd.Function):
                 (dgbd[0] if need[13] else None) if dgbd is not None else None)
 
 
+class _Block16(C.Structure):      # scnattn_block16 (include/scnattn.h)
+    _fields_ = [("N", C.c_int), ("Cin", C.c_int), ("Hi", C.c_int), ("Wi", C.c_int), ("p", C.c_int), ("stride", C.c_int),
+                ("has_down", C.c_int), ("pad", C.c_int),
+                ("gamma", C.c_void_p * 4), ("beta", C.c_void_p * 4), ("run_mean", C.c_void_p * 4), ("run_var", C.c_void_p * 4),
+                ("shift", C.c_void_p * 4), ("eps", C.c_float * 4), ("momentum", C.c_float * 4),
+                ("w", C.c_void_p * 4), ("wt", C.c_void_p * 4),
+                ("ws", C.c_void_p), ("ws_floats", C.c_long), ("part", C.c_void_p), ("bnpart", C.c_void_p), ("bnpart_floats", C.c_long),
+                ("x", C.c_void_p), ("save", C.c_void_p), ("stats", C.c_void_p),
+                ("dout", C.c_void_p), ("tmp", C.c_void_p), ("dgb", C.c_void_p), ("dw", C.c_void_p * 4), ("need_dx", C.c_int),
+                ("pad2", C.c_int), ("side_stream", C.c_void_p), ("side_ws", C.c_void_p), ("side_ws_floats", C.c_long)]
+
+
+class _Plan:
+    """Per (module, input geometry): the filled scnattn_block16 and the sizes of the three buffers the calls need."""
+
+    def __init__(self, mod, x, h):
+        N, Cin, Hi, Wi = x.shape
+        b = _Block16()
+        b.N, b.Cin, b.Hi, b.Wi, b.p, b.stride = N, Cin, Hi, Wi, mod.conv1.weight.shape[0], mod.stride
+        b.has_down = 1 if mod.downsample is not None else 0
+        sz = [C.c_long(0) for _ in range(5)]
+        _conv._chk(h.scnattn_block16_sizes(C.byref(b), *[C.byref(v) for v in sz]), "scnattn_block16_sizes")
+        self.b = b
+        self.save_elems, self.out_off, self.stats_floats, self.tmp_elems, self.dgb_floats = (v.value for v in sz)
+        self.key = (N, Cin, Hi, Wi, x.device)
+        self.bns = (mod.bn1, mod.bn2, mod.bn3) + ((mod.downsample[1],) if mod.downsample is not None else ())
+        self.convs = (mod.conv1, mod.conv2, mod.conv3) + ((mod.downsample[0],) if mod.downsample is not None else ())
+        self.C4 = 4 * b.p
+        self.Ho, self.Wo = (Hi - 1) // mod.stride + 1, (Wi - 1) // mod.stride + 1
+
+
+def _plan(mod, x, h):
+    pl = getattr(mod, "_scn_plan16", None)
+    if pl is None or pl.key != (x.shape[0], x.shape[1], x.shape[2], x.shape[3], x.device):
+        pl = _Plan(mod, x, h)
+        object.__setattr__(mod, "_scn_plan16", pl)
+    return pl
+
+
+class _Bottleneck16DriverFn(torch.autograd.Function):
+    """The same block as _Bottleneck16Fn with ONE library call per direction (csrc/block16.cpp): identical kernels on
+    identical operands in the identical order (bit-identical by test); what changes is the host's cost, ~105 -> ~35 us
+    per block forward and ~300 -> ~70 us backward, which is what bounds the bf16 step."""
+
+    @staticmethod
+    def forward(ctx, mod, x, w1, g1, b1, w2, g2, b2, w3, g3, b3, wd, gd, bd):
+        h, raw_stream = _conv._fns()
+        dev = x.device
+        st = raw_stream(dev.index)
+        if not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)
+        pl = _plan(mod, x, h)
+        b = pl.b
+        ws, part, bnpart = _conv._buffers(dev)
+        save = torch.empty(pl.save_elems, device=dev, dtype=BF)
+        stats = torch.empty(pl.stats_floats, device=dev, dtype=torch.float32)
+        for i, bn in enumerate(pl.bns):
+            b.gamma[i], b.beta[i] = bn.weight.data_ptr(), bn.bias.data_ptr()
+            b.run_mean[i], b.run_var[i] = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+            b.shift[i] = _conv._shift(bn).data_ptr()
+            b.eps[i], b.momentum[i] = bn.eps, bn.momentum
+        for i, cv in enumerate(pl.convs):
+            b.w[i], b.wt[i] = cv._w16.data_ptr(), cv._w16t.data_ptr()
+        b.ws, b.ws_floats, b.part, b.bnpart, b.bnpart_floats = ws.data_ptr(), ws.numel(), part.data_ptr(), bnpart.data_ptr(), bnpart.numel()
+        b.x, b.save, b.stats = x.data_ptr(), save.data_ptr(), stats.data_ptr()
+        _conv._chk(h.scnattn_block16_fwd(st, C.byref(b)), "scnattn_block16_fwd")
+        C4 = pl.C4
+        for i, bn in enumerate(pl.bns):       # next step's conditioning shift: this step's batch mean
+            bn._scn_shift = stats[2 * i * C4:2 * i * C4 + bn.num_features]
+        Rout = x.shape[0] * pl.Ho * pl.Wo
+        out = save[pl.out_off:pl.out_off + Rout * C4].view(Rout, C4)
+        ctx.mod, ctx.pl = mod, pl
+        ctx.save_for_backward(x, save, stats, w1, w2, w3, wd)
+        return _conv._as4d(out, x.shape[0], pl.Ho, pl.Wo)
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, raw_stream = _conv._fns()
+        x, save, stats, w1, w2, w3, wd = ctx.saved_tensors
+        mod, pl = ctx.mod, ctx.pl
+        b = pl.b
+        dev = x.device
+        st = raw_stream(dev.index)
+        need = ctx.needs_input_grad      # (mod, x, w1, g1, b1, w2, g2, b2, w3, g3, b3, wd, gd, bd)
+        if dout.dtype != BF or not dout.is_contiguous(memory_format=torch.channels_last):
+            dout = dout.to(BF).contiguous(memory_format=torch.channels_last)
+        ws, part, bnpart = _conv._buffers(dev)
+        tmp = torch.empty(pl.tmp_elems, device=dev, dtype=BF)
+        dgb = torch.empty(pl.dgb_floats, device=dev, dtype=torch.float32)
+        main = torch.cuda.current_stream(dev)
+        side = _conv._side(dev) if _conv.side_ok(w1, w2, w3, wd) else None
+        dws = [(_conv._grad_out(w) if (w is not None and need[k]) else None) for w, k in ((w1, 2), (w2, 5), (w3, 8), (wd, 11))]
+        for i, bn in enumerate(pl.bns):       # the forward call of ANOTHER input may have re-pointed the plan since
+            b.gamma[i] = bn.weight.data_ptr()
+        for i, cv in enumerate(pl.convs):
+            b.w[i], b.wt[i] = cv._w16.data_ptr(), cv._w16t.data_ptr()
+        b.ws, b.ws_floats, b.part, b.bnpart, b.bnpart_floats = ws.data_ptr(), ws.numel(), part.data_ptr(), bnpart.data_ptr(), bnpart.numel()
+        b.x, b.save, b.stats = x.data_ptr(), save.data_ptr(), stats.data_ptr()
+        b.dout, b.tmp, b.dgb = dout.data_ptr(), tmp.data_ptr(), dgb.data_ptr()
+        for i in range(4):
+            b.dw[i] = dws[i].data_ptr() if dws[i] is not None else None
+        b.need_dx = 1 if need[1] else 0
+        if side is not None:
+            b.side_stream, b.side_ws, b.side_ws_floats = side.stream.cuda_stream, side.ws.data_ptr(), side.ws.numel()
+            for t in (x, save, tmp) + tuple(d for d in dws if d is not None):
+                t.record_stream(side.stream)
+        else:
+            b.side_stream, b.side_ws, b.side_ws_floats = None, None, 0
+        dxp, dxdp = C.c_void_p(0), C.c_void_p(0)
+        _conv._chk(h.scnattn_block16_bwd(st, C.byref(b), C.byref(dxp), C.byref(dxdp)), "scnattn_block16_bwd")
+        if side is not None:
+            side.mark()
+        N, Cin, Hi, Wi = x.shape
+        dx4 = None
+        if need[1]:
+            off = (dxp.value - tmp.data_ptr()) // 2
+            dx = tmp[off:off + N * Hi * Wi * Cin].view(N * Hi * Wi, Cin)
+            if dxdp.value:
+                offd = (dxdp.value - tmp.data_ptr()) // 2
+                s = mod.stride
+                dxd = tmp[offd:offd + N * pl.Ho * pl.Wo * Cin]
+                dx.view(N, Hi, Wi, Cin)[:, ::s, ::s].add_(dxd.view(N, pl.Ho, pl.Wo, Cin))
+            dx4 = _conv._as4d(dx, N, Hi, Wi)
+        C4 = pl.C4
+
+        def gb(i, which, k, n):          # which: 0 d beta, 1 d gamma
+            return dgb[(2 * i + which) * C4:(2 * i + which) * C4 + n] if need[k] else None
+        p = b.p
+        has_down = wd is not None
+        return (None, dx4, dws[0], gb(0, 1, 3, p), gb(0, 0, 4, p), dws[1], gb(1, 1, 6, p), gb(1, 0, 7, p),
+                dws[2], gb(2, 1, 9, C4), gb(2, 0, 10, C4),
+                dws[3], gb(3, 1, 12, C4) if has_down else None, gb(3, 0, 13, C4) if has_down else None)
+
+
+BLOCK16 = os.environ.get("SCNATTN_BLOCK16", "c")     # "c": one library call per block and direction; "py": the per-launch path
+
+
 def bottleneck(mod, x):
     for bn in (mod.bn1, mod.bn2, mod.bn3) + ((mod.downsample[1],) if mod.downsample is not None else ()):
         if not bn.counter_managed and bn.num_batches_tracked is not None:
@@ -269,5 +407,6 @@ def bottleneck(mod, x):
         wd, gd, bd = mod.downsample[0].weight, mod.downsample[1].weight, mod.downsample[1].bias
     else:
         wd = gd = bd = None
-    return _Bottleneck16Fn.apply(mod, x, mod.conv1.weight, mod.bn1.weight, mod.bn1.bias, mod.conv2.weight, mod.bn2.weight,
-                                 mod.bn2.bias, mod.conv3.weight, mod.bn3.weight, mod.bn3.bias, wd, gd, bd)
+    fn = _Bottleneck16DriverFn if BLOCK16 == "c" else _Bottleneck16Fn
+    return fn.apply(mod, x, mod.conv1.weight, mod.bn1.weight, mod.bn1.bias, mod.conv2.weight, mod.bn2.weight,
+                    mod.bn2.bias, mod.conv3.weight, mod.bn3.weight, mod.bn3.bias, wd, gd, bd)

@@ -12,7 +12,8 @@ from trains.harness import TrainStep, synthetic_batch  # noqa: E402
 
 dev = torch.device("cuda:0")
 fine = "--no-finetune" not in sys.argv
-ts = TrainStep(kind="attention_scn", fine_tune_encoder=fine, device=dev)
+bf = "bf16" in sys.argv
+ts = TrainStep(kind="attention_scn", fine_tune_encoder=fine, device=dev, **({"encoder_dtype": "bf16"} if bf else {}))
 cfg = ts.cfg
 imgs, tags, caps, caplens = synthetic_batch(32, cfg["vocab_size"], cfg["max_len"], cfg["image_size"],
                                             cfg["semantic_dim"], dev, 1234)

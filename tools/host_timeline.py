@@ -19,6 +19,7 @@ os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 
 WARM = False
+BF16 = False
 
 
 def run(mode, steps):
@@ -39,7 +40,7 @@ def run(mode, steps):
         import bench
         bench.warm_miopen(dev, 32, True)
         dist.barrier()
-    ts = TrainStep(device=dev, force_reduce=(mode != "single"))
+    ts = TrainStep(device=dev, force_reduce=(mode != "single"), **({"encoder_dtype": "bf16"} if BF16 else {}))
     cfg = ts.cfg
     imgs, tags, caps, caplens = synthetic_batch(cfg["batch_size"], cfg["vocab_size"], cfg["max_len"], cfg["image_size"],
                                                 cfg["semantic_dim"], dev, 1234)
@@ -85,7 +86,9 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--modes", default="single,dist")
     ap.add_argument("--warm", action="store_true")
+    ap.add_argument("--bf16", action="store_true", help="the mixed-precision trunk (bench.py --encoder-dtype bf16)")
     a = ap.parse_args()
     WARM = a.warm
+    BF16 = a.bf16
     for m in a.modes.split(","):
         run(m, a.steps)

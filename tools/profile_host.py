@@ -10,7 +10,7 @@ from torch.profiler import profile, ProfilerActivity  # noqa: E402
 from trains.harness import TrainStep, synthetic_batch  # noqa: E402
 
 dev = torch.device("cuda:0")
-ts = TrainStep(kind="attention_scn", fine_tune_encoder=True, device=dev)
+ts = TrainStep(kind="attention_scn", fine_tune_encoder=True, device=dev, **({"encoder_dtype": "bf16"} if "bf16" in sys.argv else {}))
 cfg = ts.cfg
 imgs, tags, caps, caplens = synthetic_batch(32, cfg["vocab_size"], cfg["max_len"], cfg["image_size"], cfg["semantic_dim"], dev, 1)
 for _ in range(6):
