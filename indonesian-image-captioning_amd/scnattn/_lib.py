@@ -157,6 +157,11 @@ def lib():
                 fn.restype = res
             h.scnattn_last_error.argtypes = []
             h.scnattn_last_error.restype = C.c_char_p
+            # A/B runs without touching code: SCNATTN_OPTIONS="cgemm_combine=0,dec_tail=1" (scnattn_set_option names)
+            for item in filter(None, os.environ.get("SCNATTN_OPTIONS", "").split(",")):
+                name, _, val = item.partition("=")
+                if h.scnattn_set_option(name.strip().encode(), int(val)) != 0:
+                    raise RuntimeError("SCNATTN_OPTIONS: %s" % h.scnattn_last_error().decode())
             _lib = h
     return _lib
 

@@ -179,7 +179,7 @@ def test_end_to_end_training_from_hdf5_files_learns(dev, tmp_path):
     loader = SD.DeviceBatchLoader(str(tmp_path), base, "TRAIN", 8, dev, cpi=1, shuffle=True, seed=0)
     tags_all = torch.rand(N, 10, device=dev)
     losses = []
-    for epoch in range(30):
+    for epoch in range(45):     # 30 epochs end at 49-55 % of the first loss over the builds of rounds 2-3: on the bar; 45 clear it
         loader.set_epoch(epoch)
         order = SD.epoch_order(N, epoch, 0, True)
         for b, (imgs, caps, caplens) in enumerate(loader):
