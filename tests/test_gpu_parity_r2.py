@@ -265,9 +265,9 @@ def test_pure_attention_full_width_mask_unambiguous(dev):
     asserted, outputs 1e-4 and every gradient 2e-4; both the dense and the pooled path.  One stated exception: in this
     construction d att2 survives the softmax's shift invariance only through the variation of the ReLU mask over the
     pixels, a difference of near-equal sums, and the reference's OWN fp32 evaluation on the CPU is 1.6-2.0e-4 from fp64
-    for attention.decoder_att.{weight,bias} and attention.encoder_att.bias (computed below, not assumed).  A tensor whose
-    CPU-fp32 distance exceeds 7e-5 is therefore allowed 3x that distance; the measured GPU errors moved between 5.6e-5
-    and 2.7e-4 over four builds that differ only in summation order -- the spread of that yardstick."""
+    for attention.decoder_att.{weight,bias} and attention.encoder_att.bias (computed below, not assumed).  These three
+    are allowed 3x the largest of their CPU-fp32 distances; the measured GPU errors moved between 5.6e-5 and 2.7e-4
+    over four builds that differ only in summation order -- the spread of that yardstick."""
     from models.decoders.pure_attention import PureAttention
     from oracle import scnattn_ref as R
     torch.manual_seed(5)
@@ -284,13 +284,10 @@ def test_pure_attention_full_width_mask_unambiguous(dev):
     r64 = _oracle_run("pure_attention", sd, x, None, caps, caplens, None, si, torch.float64, probe=True)
     assert r64[4] > 1e-3, "ReLU margin %.3e" % r64[4]
     r32 = _oracle_run("pure_attention", sd, x, None, caps, caplens, None, si, torch.float32)
-    floors = {}
-    for k, v in r64[3].items():
-        e32 = rel_err(r32[3][k], v)
-        if 7e-5 < e32 < 1e-3:
-            floors[k] = 3.0 * e32
-    assert set(floors) <= {"attention.decoder_att.weight", "attention.decoder_att.bias", "attention.encoder_att.bias",
-                           "attention.encoder_att.weight", "__x"}, floors
+    family = ("attention.decoder_att.weight", "attention.decoder_att.bias", "attention.encoder_att.bias")   # all fed by d att2
+    e32 = max(rel_err(r32[3][k], r64[3][k]) for k in family)
+    assert 3e-5 < e32 < 1e-3, e32          # the yardstick itself: 1.6-2.0e-4 on the build box's CPU
+    floors = {k: 3.0 * e32 for k in family}
     hip = _hip_run("pure_attention", copy.deepcopy(m), x, None, caps, caplens, None, si, dev)
     _compare("pure_attention", m, hip, r64, floors, "pure_attention full width pooled, margin %.3f" % r64[4])
     mg = copy.deepcopy(m).to(dev).train()
