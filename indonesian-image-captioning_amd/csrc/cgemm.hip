@@ -36,7 +36,6 @@
 //     cannot fill 256 CUs.
 #include "common.h"
 #include "kernels.h"
-#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <type_traits>
@@ -1228,13 +1227,6 @@ int cgemm(hipStream_t st, bool tA, bool tB, int M, int N, int K, float alpha, co
         while (S > 1 && (long)S * batch * M * N > ws_floats) --S;
         if (S < 1) S = 1;
     }
-    // One workgroup per CU and a statistics epilogue (layer3's conv1 forward, 8192 x 256 x 1024): two K-slices finished in
-    // the launch (49.1 -> 46.1 us stand-alone, tools/split_sweep.py) -- the second resident workgroup covers the first one's
-    // ring fill and epilogue; the same product without the epilogue does not gain (45.5 vs 46.0).
-    static const bool ab_off = getenv("SCNATTN_AB_NO_S2") != nullptr;
-    if (!ab_off && ws && !c3 && S == 1 && epi == 1 && tiles >= 224 && tiles <= 320 && K >= 1024 && g_cgemm_target == 512 && g_cgemm_combine &&
-        (long)2 * batch * M * N <= ws_floats)
-        S = 2;
     if (c3 == 4) S = 1;       // the four parity classes ride on grid.y; their K (1, 2, 2, 4 taps) is never split
     if ((c3 == 1 || c3 == 2) && ws) {   // deep K (9 taps): 128-row tiles, up to 4 K-slices to reach ~512 workgroups (measured)
         S = (int)(512 / (tiles > 0 ? tiles : 1));
