@@ -23,3 +23,21 @@ for (R,Cin,Cout) in [(8192,1024,256),(2048,2048,512),(8192,256,1024),(2048,512,2
             f=d=float('nan')
         row.append((f,d))
     print("R=%6d Cin=%5d Cout=%5d | fwd+stats at split 1..4: %s | dgrad: %s" % (R,Cin,Cout," ".join("%6.1f"%r[0] for r in row)," ".join("%6.1f"%r[1] for r in row)), flush=True)
+
+# weight gradients of layer3 / layer2 (K = rows): forced split, two-launch protocol vs in-launch combine
+from scnattn import functional as SF
+print("wgrad dW[Cout][Cin] = dy^T x: us at forced split (two launches | in-launch combine)")
+for (R, Cin, Cout) in [(8192, 1024, 256), (8192, 256, 1024), (32768, 512, 128), (32768, 128, 512), (2048, 2048, 512)]:
+    x = torch.randn(R, Cin, device=dev); dy = torch.randn(R, Cout, device=dev); dw = torch.empty(Cout, Cin, device=dev)
+    out = []
+    for fs in (4, 8, 16, 32):
+        row = []
+        for comb in (0, 1):
+            SF.set_option("cgemm_combine", comb); SF.set_option("cgemm_combine_max", 64)
+            try:
+                row.append(cb.t_us(lambda: cb.cgemm(dy, x, True, False, dw, Cout, Cin, R, ConvExtra(force_split=fs))))
+            except Exception:
+                row.append(float("nan"))
+        out.append("S=%-2d %5.1f | %5.1f" % (fs, row[0], row[1]))
+    print("R=%6d Cin=%5d Cout=%5d | %s" % (R, Cin, Cout, "   ".join(out)), flush=True)
+SF.set_option("cgemm_combine", 1); SF.set_option("cgemm_combine_max", 8)
