@@ -399,6 +399,7 @@ class _Bottleneck16DriverFn(torch.autograd.Function):
 BLOCK16 = os.environ.get("SCNATTN_BLOCK16", "c")     # "c": one library call per block and direction; "py": the per-launch path
 
 
+
 def bottleneck(mod, x):
     for bn in (mod.bn1, mod.bn2, mod.bn3) + ((mod.downsample[1],) if mod.downsample is not None else ()):
         if not bn.counter_managed and bn.num_batches_tracked is not None:

@@ -397,10 +397,13 @@ def test_bf16_block_driver_is_bit_identical_to_the_per_launch_path(dev, inplanes
     """csrc/block16.cpp (scnattn_block16_fwd / _bwd: one library call per Bottleneck and direction, the default of the bf16
     trunk) enqueues the same kernels on the same operands in the same order as scnattn/conv16.py's per-launch path
     (SCNATTN_BLOCK16=py): output, d x, every weight / gamma / beta gradient and the running statistics must be
-    bit-identical, for identity blocks and the three kinds of down-sampling block, over two consecutive steps (the second
-    step's conditioning shift is the first step's batch mean on both paths)."""
+    bit-identical, for identity blocks and the three kinds of down-sampling block, over four consecutive steps (a step's
+    conditioning shift is the previous step's batch mean on both paths).  Parameters live in a flat buffer
+    (utils.optimizer.FusedClampAdam) as in the train step.  (A third path, the same sequences replayed from HIP graphs,
+    passed this test too and was removed for being slower: profiles/r03_bf16_block_hip_graph_replay_rejected.txt.)"""
     from scnattn.resnet import Bottleneck, FusedBatchNorm2d
     from scnattn import conv16 as C16
+    from utils.optimizer import FusedClampAdam
     from torch import nn
     torch.manual_seed(77 + H + planes)
     down = None
@@ -408,7 +411,7 @@ def test_bf16_block_driver_is_bit_identical_to_the_per_launch_path(dev, inplanes
         down = nn.Sequential(nn.Conv2d(inplanes, planes * 4, kernel_size=1, stride=stride, bias=False), FusedBatchNorm2d(planes * 4))
     m = Bottleneck(inplanes, planes, stride, down).train()
     N = 8
-    xs = [(torch.relu(torch.randn(N, inplanes, H, H)) + 0.1 * torch.randn(N, inplanes, H, H)).to(torch.bfloat16) for _ in range(2)]
+    xs = [(torch.relu(torch.randn(N, inplanes, H, H)) + 0.1 * torch.randn(N, inplanes, H, H)).to(torch.bfloat16) for _ in range(4)]
     wg = None
     res = {}
     old = C16.BLOCK16
@@ -416,16 +419,16 @@ def test_bf16_block_driver_is_bit_identical_to_the_per_launch_path(dev, inplanes
         for mode in ("py", "c"):
             C16.BLOCK16 = mode
             g = copy.deepcopy(m).to(dev).to(memory_format=torch.channels_last).train()
+            opt = FusedClampAdam(list(g.parameters()), lr=0.0, grad_clip=5.0)
             outs = []
             for x in xs:
                 C16.refresh_weights(g)
                 xg = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
                 assert C16.usable(g, xg)
+                opt.zero_grad()
                 y = g(xg)
                 if wg is None:
                     wg = torch.randn_like(y)
-                for p in g.parameters():
-                    p.grad = None
                 y.backward(wg)
                 torch.cuda.synchronize()
                 outs.append((y.detach().clone(), xg.grad.clone(), {k: p.grad.clone() for k, p in g.named_parameters()},
@@ -433,13 +436,14 @@ def test_bf16_block_driver_is_bit_identical_to_the_per_launch_path(dev, inplanes
             res[mode] = outs
     finally:
         C16.BLOCK16 = old
-    for (y0, dx0, g0, b0), (y1, dx1, g1, b1) in zip(res["py"], res["c"]):
-        assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
-        assert set(g0) == set(g1) and all(v is not None for v in g0.values())
-        for k in g0:
-            assert torch.equal(g0[k], g1[k]), k
-        for k in b0:
-            assert torch.equal(b0[k], b1[k]), k
+    for mode in ("c",):
+        for (y0, dx0, g0, b0), (y1, dx1, g1, b1) in zip(res["py"], res[mode]):
+            assert torch.equal(y0, y1) and torch.equal(dx0, dx1), mode
+            assert set(g0) == set(g1) and all(v is not None for v in g0.values())
+            for k in g0:
+                assert torch.equal(g0[k], g1[k]), (mode, k)
+            for k in b0:
+                assert torch.equal(b0[k], b1[k]), (mode, k)
 
 
 def test_bf16_train_step_runs_on_the_hand_written_trunk_and_learns(dev):
