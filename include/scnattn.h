@@ -404,6 +404,10 @@ int scnattn_bn_bwd_dx_fin(void* stream, long R, int C, const void* g, const void
  *                          ex: epi 1 (statistics of C from the fp32 accumulators, channel-major partials), stride (row
  *                          gather of a strided 1x1 convolution); a 1x1 d input is this with B = the transposed copy;
  *   scnattn_conv3x3_fwd16 / _dgrad16   implicit GEMMs as in fp32 (taps over K; stride-2 d input by parity classes);
+ *                          epi 2 (scnattn_cgemm16 with a bf16 output, and the stride-1 _dgrad16; ex->ez is then the consumer
+ *                          BatchNorm's bf16 pre-activation): the ReLU mask recomputed with the forward pass's expression,
+ *                          g stored, column sums of g and g*xhat as channel-major partials -- that BatchNorm's backward
+ *                          reduce pass inside the d-input product (the product then runs un-split);
  *   scnattn_wgrad16_3x3    dw [Cout][3][3][Cin] fp32 of a stride-1 3x3 convolution from bf16 maps: contraction over pixels
  *                          with both operands read through the transposing LDS load (ds_read_b64_tr_b16), halo staged once;
  *   scnattn_wgrad16_rows   dw[co][ci] (ldo) = sum_r dy[r][co] * x[src(r)][ci]: 1x1 weight gradients (gs = 0), the strided
@@ -418,7 +422,7 @@ int scnattn_cgemm16(void* stream, int M, int N, int K, const void* A, long lda, 
 int scnattn_conv3x3_fwd16(void* stream, int N, int Hi, int Wi, int Cin, int Cout, int stride, const void* x, const void* w,
                           void* y, const scnattn_conv_extra* ex, float* ws, long ws_floats);
 int scnattn_conv3x3_dgrad16(void* stream, int N, int Hi, int Wi, int Cin, int Cout, int stride, const void* dy, const void* wt,
-                            void* dx, float* ws, long ws_floats);
+                            void* dx, const scnattn_conv_extra* ex, float* ws, long ws_floats);
 int scnattn_wgrad16_3x3(void* stream, int N, int H, int W, int Cin, int Cout, const void* dy, const void* x, float* dw,
                         float* ws, long ws_floats, int k_slices);
 int scnattn_wgrad16_rows(void* stream, int R, int Cin, int Cout, const void* dy, const void* x, long src_rows, float* dw,

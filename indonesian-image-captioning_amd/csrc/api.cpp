@@ -272,9 +272,10 @@ int scnattn_conv3x3_fwd16(void* stream, int N, int Hi, int Wi, int Cin, int Cout
 // wt: the TRANSPOSED bf16 weight copy [Cin][3][3][Cout] (scnattn_bf16_weights).  stride 1: a forward convolution of dy with
 // flipped taps; stride 2: four parity classes in one launch.
 int scnattn_conv3x3_dgrad16(void* stream, int N, int Hi, int Wi, int Cin, int Cout, int stride, const void* dy, const void* wt,
-                            void* dx, float* ws, long ws_floats) {
+                            void* dx, const scnattn_conv_extra* ex, float* ws, long ws_floats) {
     SCN_ARG(N > 0 && Hi > 0 && Wi > 0 && (stride == 1 || (stride == 2 && Hi % 2 == 0 && Wi % 2 == 0)), "conv3x3_dgrad16: geometry");
-    ConvExtra e;
+    ConvExtra e = to_extra(ex);
+    SCN_ARG(stride == 1 || e.epi == 0, "conv3x3_dgrad16: the mask epilogue serves the stride-1 form only");
     if (stride == 1) {
         e.c3 = 1; e.c3c = Cout; e.c3_src_rows = (long)N * Hi * Wi; e.Hi = Hi; e.Wi = Wi; e.Ho = Hi; e.Wo = Wi; e.stride = 1;
         return cgemm16(ST(stream), N * Hi * Wi, Cin, 9 * Cout, dy, Cout, wt, 9L * Cout, 0.f, dx, Cin, 1, ws, ws ? ws_floats : 0, &e, 1);

@@ -164,9 +164,21 @@ int scnattn_block16_bwd(void* st, const scnattn_block16* b, void** dx_out, void*
                                      static_cast<float*>(wsw), wsn, 0));
     }
     // ---- conv3 d input, bn2 --------------------------------------------------------------------------------------------------
-    SCN_TRY(scnattn_cgemm16(st, Rout, p, C4, T(c.dz3), C4, b->wt[2], C4, 0.f, T(c.dz2), p, 1, b->ws, b->ws_floats, nullptr));
-    SCN_TRY(reduce(1, Rout, p, T(c.dz2), S(c.a2), S(c.z2), 1, T(c.dz2), &nch));       // g in place of d a2
-    SCN_TRY(dxfin(1, Rout, p, T(c.dz2), S(c.z2), nch, T(c.dz2)));
+    // the d-input product writes g2 = d a2 * [a2 > 0] and the two sums of bn2's backward itself (mask epilogue): no reduce pass
+    auto mask_ex = [&](int i, const void* z, int Cn) {
+        scnattn_conv_extra e{};
+        e.epi = 2; e.stat_partial = b->bnpart; e.ez = static_cast<const float*>(z); e.ldz = Cn;
+        e.emean = mean(i); e.einvstd = istd(i); e.egamma = b->gamma[i]; e.ebeta = b->beta[i];
+        return e;
+    };
+    SCN_ARG(2L * p * scnattn_cgemm_stat_ld(Rin) <= b->bnpart_floats, "block16_bwd: bnpart too small for the mask epilogue's partials");
+    {
+        const scnattn_conv_extra e2 = mask_ex(1, S(c.z2), p);
+        SCN_TRY(scnattn_cgemm16(st, Rout, p, C4, T(c.dz3), C4, b->wt[2], C4, 0.f, T(c.dz2), p, 1, b->ws, b->ws_floats, &e2));
+        nch = scnattn_cgemm_row_tiles(Rout);
+        SCN_TRY(scnattn_bn_bwd_dx_fin(st, Rout, p, T(c.dz2), S(c.z2), 1, mean(1), istd(1), b->gamma[1], b->bnpart,
+                                      scnattn_cgemm_stat_ld(Rout), nch, dbeta(1), dgamma(1), T(c.dz2)));
+    }
     // ---- conv2: weight gradient, d input, bn1 --------------------------------------------------------------------------------
     if (b->dw[1]) {
         SCN_TRY(fork());
@@ -179,9 +191,17 @@ int scnattn_block16_bwd(void* st, const scnattn_block16* b, void** dx_out, void*
                                              b->Wi, Ho, Wo, tap / 3 - 1, tap % 3 - 1, static_cast<float*>(wsw), wsn, 0));
         }
     }
-    SCN_TRY(scnattn_conv3x3_dgrad16(st, b->N, b->Hi, b->Wi, p, p, s, T(c.dz2), b->wt[1], T(c.dz1), b->ws, b->ws_floats));
-    SCN_TRY(reduce(0, Rin, p, T(c.dz1), S(c.a1), S(c.z1), 1, T(c.dz1), &nch));
-    SCN_TRY(dxfin(0, Rin, p, T(c.dz1), S(c.z1), nch, T(c.dz1)));
+    if (s == 1) {       // mask epilogue with bn1
+        const scnattn_conv_extra e1 = mask_ex(0, S(c.z1), p);
+        SCN_TRY(scnattn_conv3x3_dgrad16(st, b->N, b->Hi, b->Wi, p, p, 1, T(c.dz2), b->wt[1], T(c.dz1), &e1, b->ws, b->ws_floats));
+        nch = scnattn_cgemm_row_tiles(Rin);
+        SCN_TRY(scnattn_bn_bwd_dx_fin(st, Rin, p, T(c.dz1), S(c.z1), 1, mean(0), istd(0), b->gamma[0], b->bnpart,
+                                      scnattn_cgemm_stat_ld(Rin), nch, dbeta(0), dgamma(0), T(c.dz1)));
+    } else {            // parity classes write scattered rows: the reduce pass stays
+        SCN_TRY(scnattn_conv3x3_dgrad16(st, b->N, b->Hi, b->Wi, p, p, s, T(c.dz2), b->wt[1], T(c.dz1), nullptr, b->ws, b->ws_floats));
+        SCN_TRY(reduce(0, Rin, p, T(c.dz1), S(c.a1), S(c.z1), 1, T(c.dz1), &nch));
+        SCN_TRY(dxfin(0, Rin, p, T(c.dz1), S(c.z1), nch, T(c.dz1)));
+    }
     if (b->dw[0]) {
         SCN_TRY(fork());
         sw = wstream(&wsw, &wsn);

@@ -50,6 +50,7 @@ struct HArgs {
     int dHi, dWi;                 // mode 4: extent of the d-input map the rows are scattered into
     int flip;                     // mode 1: weight tap = 8 - t (a stride-1 d input as a forward convolution of dY)
     float* stat_partial; const float* stat_shift; int ldp;
+    const bf16_t* ez; long ldz; const float* emean; const float* einvstd; const float* egamma; const float* ebeta;   // EPI 2
 };
 
 __device__ __forceinline__ long gather_row(const HArgs& g, int r) {
@@ -81,6 +82,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // MI: 32-row MFMA tiles per wave along m (block tile 64*MI x 128, waves 2 x 2).  EPI 1: + column statistics.
+// EPI 2 (bf16 output, un-split d-input products): g = dx * [relu mask of the consumer BatchNorm recomputed from its bf16
+// pre-activation z with the forward pass's own expression] stored, + column sums of g and g*xhat per 64-row block -- the
+// reduce pass of that BatchNorm's backward inside the product that feeds it (as EPI 2 of csrc/cgemm.hip).
 // GATHER: rows of A are gathered (strided 1x1 convolution).  OBF: C is bf16.  C3: 0 plain, 1 3x3 taps over K (forward, or a
 // stride-1 d input with `flip`), 4 stride-2 d input, one parity class per blockIdx.y.
 template <int MI, int EPI, bool GATHER, bool OBF, int C3>
@@ -313,14 +317,33 @@ __global__ __launch_bounds__(256, 3) void cgemm16_kernel(HArgs g) {
         const __amdgpu_buffer_rsrc_t ors = make_rsrc(Cb, (unsigned)(((out_rows - 1) * g.ldc + g.N) * 2));
         const int rl = lane >> 3, c8 = (lane & 7) * 8, ncol = n0 + wn * 64 + c8;
         const bool use_c = g.beta != 0.f;
+        [[maybe_unused]] float mu[8], is[8], ga[8], be[8], s1[8], s2[8];
+        [[maybe_unused]] const __amdgpu_buffer_rsrc_t zrs = make_rsrc(g.ez, EPI == 2 ? (unsigned)(((long)(g.M - 1) * g.ldz + g.N) * 2) : 0u);
+        if constexpr (EPI == 2) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const bool ok = ncol + q < g.N;
+                mu[q] = ok ? g.emean[ncol + q] : 0.f; is[q] = ok ? g.einvstd[ncol + q] : 0.f;
+                ga[q] = ok ? g.egamma[ncol + q] : 0.f; be[q] = ok ? g.ebeta[ncol + q] : 0.f;
+                s1[q] = 0.f; s2[q] = 0.f;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             u32x4 cv[4];
+            [[maybe_unused]] u32x4 zv[4];
             if (use_c) {
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int m = mw0 + i * 32 + it * 8 + rl;
                     cv[it] = __builtin_amdgcn_raw_buffer_load_b128(ors, (m < g.M && ncol < g.N) ? (unsigned)((row_of(m) * g.ldc + ncol) * 2) + opq : OOB_OFF, 0, 0);
+                }
+            }
+            if constexpr (EPI == 2) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int m = mw0 + i * 32 + it * 8 + rl;
+                    zv[it] = __builtin_amdgcn_raw_buffer_load_b128(zrs, (m < g.M && ncol < g.N) ? (unsigned)(((long)m * g.ldz + ncol) * 2) + opq : OOB_OFF, 0, 0);
                 }
             }
             dump_half(i);
@@ -337,10 +360,59 @@ __global__ __launch_bounds__(256, 3) void cgemm16_kernel(HArgs g) {
                         v1[2 * q + 1] = fmaf(g.beta, bf16_to_f32(cv[it][2 + q] >> 16), v1[2 * q + 1]);
                     }
                 }
+                if constexpr (EPI == 2) {
+                    float vv[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const unsigned w = zv[it][q >> 1];
+                        const float z = bf16_to_f32((q & 1) ? (w >> 16) : (w & 0xffffu));
+                        const float xh = (z - mu[q]) * is[q];
+                        const bool on = m < g.M && fmaf(xh, ga[q], be[q]) > 0.f;     // the forward pass's expression (csrc/batchnorm.hip)
+                        // the sums are taken of the bf16 rounding of g: what the consumers will read
+                        vv[q] = on ? bf16_to_f32(pack2(vv[q], 0.f) & 0xffffu) : 0.f;
+                        s1[q] += vv[q];
+                        s2[q] = fmaf(vv[q], xh, s2[q]);
+                    }
+                    v0 = f32x4{vv[0], vv[1], vv[2], vv[3]};
+                    v1 = f32x4{vv[4], vv[5], vv[6], vv[7]};
+                }
                 const u32x4 o = {pack2(v0[0], v0[1]), pack2(v0[2], v0[3]), pack2(v1[0], v1[1]), pack2(v1[2], v1[3])};
                 __builtin_amdgcn_raw_buffer_store_b128(o, ors, (m < g.M && ncol < g.N) ? (unsigned)((row_of(m) * g.ldc + ncol) * 2) + opq : OOB_OFF, 0, 0);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if constexpr (EPI == 2) {        // column sums of this wave's RB*32 rows -> one partial per 64-row block
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                s1[q] += __shfl_xor(s1[q], 8, 64); s1[q] += __shfl_xor(s1[q], 16, 64); s1[q] += __shfl_xor(s1[q], 32, 64);
+                s2[q] += __shfl_xor(s2[q], 8, 64); s2[q] += __shfl_xor(s2[q], 16, 64); s2[q] += __shfl_xor(s2[q], 32, 64);
+            }
+            if (MI == 2) {
+                if (lane < 8 && mw0 < g.M) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (ncol + q < g.N) {
+                            float* p = g.stat_partial + (long)(ncol + q) * g.ldp + (tm * 2 + wm);
+                            p[0] = s1[q];
+                            p[(long)g.N * g.ldp] = s2[q];
+                        }
+                }
+            } else {
+                if (lane < 8) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        colsum[(wm * 2 + 0) * TN + wn * 64 + c8 + q] = s1[q];
+                        colsum[(wm * 2 + 1) * TN + wn * 64 + c8 + q] = s2[q];
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (tid < TN && n0 + tid < g.N) {
+                    float* p = g.stat_partial + (long)(n0 + tid) * g.ldp + tm;
+                    p[0] = colsum[0 * TN + tid] + colsum[2 * TN + tid];
+                    p[(long)g.N * g.ldp] = colsum[1 * TN + tid] + colsum[3 * TN + tid];
+                }
+            }
         }
     } else {                        // fp32 rows
         float* const Cf = reinterpret_cast<float*>(g.C);
@@ -459,8 +531,10 @@ void launch16(hipStream_t st, dim3 grid, const HArgs& g, int kepi, bool gather, 
 #define SCN_L16(EPI_, G_, O_) hipLaunchKernelGGL((cgemm16_kernel<MI, EPI_, G_, O_, C3>), grid, block, 0, st, g)
     if constexpr (C3 == 0) {
         if (gather) { if (kepi) { if (obf) SCN_L16(1, true, true); else SCN_L16(1, true, false); } else { if (obf) SCN_L16(0, true, true); else SCN_L16(0, true, false); } }
+        else if (kepi == 2) SCN_L16(2, false, true);
         else        { if (kepi) { if (obf) SCN_L16(1, false, true); else SCN_L16(1, false, false); } else { if (obf) SCN_L16(0, false, true); else SCN_L16(0, false, false); } }
     } else {        // 3x3 modes always write bf16 maps
+        if constexpr (C3 == 1) { if (kepi == 2) { SCN_L16(2, false, true); return; } }
         if (kepi) SCN_L16(1, false, true); else SCN_L16(0, false, true);
     }
 #undef SCN_L16
@@ -479,7 +553,10 @@ int cgemm16(hipStream_t st, int M, int N, int K, const void* A, long lda, const 
     SCN_ARG(N % 8 == 0 && ldc % (out_bf16 ? 8 : 4) == 0, "cgemm16: N / ldc granularity");
     const int epi = ex ? ex->epi : 0, c3 = ex ? ex->c3 : 0;
     const bool gather = ex && ex->stride > 1 && c3 == 0;
-    SCN_ARG(epi == 0 || (epi == 1 && ex->stat_partial && beta == 0.f), "cgemm16: statistics epilogue needs a plain product (epi 0 / 1 only)");
+    SCN_ARG(epi == 0 || ((epi == 1 || epi == 2) && ex->stat_partial && beta == 0.f), "cgemm16: statistics / mask epilogue needs a plain product");
+    SCN_ARG(epi != 2 || (out_bf16 && !gather && c3 != 4 && ex->ez && ex->emean && ex->einvstd && ex->egamma && ex->ebeta && ex->ldz % 8 == 0 &&
+                         aligned16(ex->ez) && ((long)(M - 1) * ex->ldz + N) * 2 < 0x7fffffffL),
+            "cgemm16: mask epilogue needs a bf16 output, an un-gathered product and the consumer BatchNorm's z / mean / invstd / gamma / beta");
     SCN_ARG(!ex || ex->pro == 0, "cgemm16: no prologue in the bf16 path (the normalised map is materialised)");
     if (c3) {
         SCN_ARG((c3 == 1 || c3 == 4) && out_bf16 && beta == 0.f, "cgemm16: 3x3 modes 1 / 4, bf16 output");
@@ -504,7 +581,8 @@ int cgemm16(hipStream_t st, int M, int N, int K, const void* A, long lda, const 
         while (S > 1 && (long)S * M * N > ws_floats) --S;
         if (S < 1) S = 1;
     }
-    if (ex && ex->force_split > 0 && c3 != 4) {
+    if (epi == 2) S = 1;        // the mask epilogue lives in the product's own launch: un-split (only layer4's shapes would split)
+    if (ex && ex->force_split > 0 && c3 != 4 && epi != 2) {
         S = ex->force_split;
         SCN_ARG(S == 1 || (ws && (long)S * M * N <= ws_floats && S <= 64), "cgemm16: forced split does not fit");
     }
@@ -519,6 +597,7 @@ int cgemm16(hipStream_t st, int M, int N, int K, const void* A, long lda, const 
         g.c3c = ex->c3c; g.src_rows = ex->c3_src_rows;
         if (c3 == 4) { g.gHi = ex->Ho; g.gWi = ex->Wo; g.dHi = ex->Hi; g.dWi = ex->Wi; }
         g.stat_partial = ex->stat_partial; g.stat_shift = ex->stat_shift; g.ldp = cgemm_stat_ld(M);
+        g.ez = (const bf16_t*)ex->ez; g.ldz = ex->ldz; g.emean = ex->emean; g.einvstd = ex->einvstd; g.egamma = ex->egamma; g.ebeta = ex->ebeta;
     }
     dim3 grid(mt * nt, c3 == 4 ? 4 : S);
     const int kepi = S > 1 ? 0 : epi;

@@ -85,7 +85,7 @@ _SIGS = {
     "scnattn_bf16_weights": ([vp, i32, vp, vp, i32], i32),
     "scnattn_cgemm16": ([vp, i32, i32, i32, vp, i64, vp, i64, f32, vp, i64, i32, vp, i64, C.POINTER(ConvExtra)], i32),
     "scnattn_conv3x3_fwd16": ([vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, C.POINTER(ConvExtra), vp, i64], i32),
-    "scnattn_conv3x3_dgrad16": ([vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i64], i32),
+    "scnattn_conv3x3_dgrad16": ([vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, C.POINTER(ConvExtra), vp, i64], i32),
     "scnattn_wgrad16_3x3": ([vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i64, i32], i32),
     "scnattn_block16_sizes": ([vp, vp, vp, vp, vp, vp], i32),
     "scnattn_block16_fwd": ([vp, vp], i32),

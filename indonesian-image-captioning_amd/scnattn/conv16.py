@@ -201,11 +201,13 @@ class _Bottleneck16Fn(torch.autograd.Function):
             _chk(h.scnattn_wgrad16_rows(sw, Rout, p, C4, dz3.data_ptr(), a2.data_ptr(), Rout, dw3.data_ptr(), p, 0, 0, 0, 0, 0,
                                         0, 0, wsw.data_ptr(), wsw.numel(), 0), "scnattn_wgrad16_rows")
         # ---- conv3 d input, bn2 ---------------------------------------------------------------------------------------------
-        da2 = torch.empty((Rout, p), **bf)
-        _mm(h, st, Rout, p, C4, dz3, C4, mod.conv3._w16t, C4, da2, p, ws)
-        dz2, nch = _red(h, st, Rout, p, da2, a2, z2, st2, True, bnpart, True)
-        dgb2 = _dx(h, st, Rout, p, dz2, z2, st2, g2, bnpart, (nch + 3) & ~3, nch, dz2)
-        del da2
+        # the d-input product writes g2 = d a2 * [a2 > 0] and the two sums of bn2's backward itself (mask epilogue)
+        def mask_ex(z, stats, bn_mod, Cn):
+            return ConvExtra(epi=2, stat_partial=bnpart.data_ptr(), ez=z.data_ptr(), ldz=Cn, emean=stats[0].data_ptr(),
+                             einvstd=stats[1].data_ptr(), egamma=bn_mod.weight.data_ptr(), ebeta=bn_mod.bias.data_ptr())
+        dz2 = torch.empty((Rout, p), **bf)
+        _mm(h, st, Rout, p, C4, dz3, C4, mod.conv3._w16t, C4, dz2, p, ws, mask_ex(z2, st2, mod.bn2, p))
+        dgb2 = _dx(h, st, Rout, p, dz2, z2, st2, g2, bnpart, h.scnattn_cgemm_stat_ld(Rout), h.scnattn_cgemm_row_tiles(Rout), dz2)
         # ---- conv2: weight gradient (side stream), d input, bn1 ------------------------------------------------------------
         dw2 = None
         if need[5]:
@@ -219,12 +221,17 @@ class _Bottleneck16Fn(torch.autograd.Function):
                     _chk(h.scnattn_wgrad16_rows(sw, Rout, p, p, dz2.data_ptr(), a1.data_ptr(), Rin,
                                                 dw2.data_ptr() + 4 * tap * p, 9 * p, s, Hi, Wi, Ho, Wo, tap // 3 - 1, tap % 3 - 1,
                                                 wsw.data_ptr(), wsw.numel(), 0), "scnattn_wgrad16_rows")
-        da1 = torch.empty((Rin, p), **bf)
-        _chk(h.scnattn_conv3x3_dgrad16(st, N, Hi, Wi, p, p, s, dz2.data_ptr(), mod.conv2._w16t.data_ptr(), da1.data_ptr(),
-                                       ws.data_ptr(), ws.numel()), "scnattn_conv3x3_dgrad16")
-        dz1, nch = _red(h, st, Rin, p, da1, a1, z1, st1, True, bnpart, True)
-        dgb1 = _dx(h, st, Rin, p, dz1, z1, st1, g1, bnpart, (nch + 3) & ~3, nch, dz1)
-        del da1
+        dz1 = torch.empty((Rin, p), **bf)
+        if s == 1:      # mask epilogue with bn1
+            ex1 = mask_ex(z1, st1, mod.bn1, p)
+            _chk(h.scnattn_conv3x3_dgrad16(st, N, Hi, Wi, p, p, 1, dz2.data_ptr(), mod.conv2._w16t.data_ptr(), dz1.data_ptr(),
+                                           C.byref(ex1), ws.data_ptr(), ws.numel()), "scnattn_conv3x3_dgrad16")
+            dgb1 = _dx(h, st, Rin, p, dz1, z1, st1, g1, bnpart, h.scnattn_cgemm_stat_ld(Rin), h.scnattn_cgemm_row_tiles(Rin), dz1)
+        else:           # parity classes write scattered rows: the reduce pass stays
+            _chk(h.scnattn_conv3x3_dgrad16(st, N, Hi, Wi, p, p, s, dz2.data_ptr(), mod.conv2._w16t.data_ptr(), dz1.data_ptr(),
+                                           None, ws.data_ptr(), ws.numel()), "scnattn_conv3x3_dgrad16")
+            dz1, nch = _red(h, st, Rin, p, dz1, a1, z1, st1, True, bnpart, True)
+            dgb1 = _dx(h, st, Rin, p, dz1, z1, st1, g1, bnpart, (nch + 3) & ~3, nch, dz1)
         dw1 = None
         if need[2]:
             dw1 = _conv._grad_out(w1)

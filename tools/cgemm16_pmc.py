@@ -36,7 +36,7 @@ jobs = [
     ("conv2 fwd  3x3 256->256   (cgemm16 implicit GEMM + statistics)", 2.0 * R * p * 9 * p, 2 * (R * p + 9 * p * p + R * p),
      lambda: call("scnattn_conv3x3_fwd16", st, N, H, H, p, p, 1, ptr(a1), ptr(w2), ptr(z2), C.byref(ex), ptr(WS), WS.numel())),
     ("conv2 dgrad 3x3           (cgemm16 implicit GEMM)", 2.0 * R * p * 9 * p, 2 * (R * p + 9 * p * p + R * p),
-     lambda: call("scnattn_conv3x3_dgrad16", st, N, H, H, p, p, 1, ptr(dz2), ptr(w2), ptr(da1), ptr(WS), WS.numel())),
+     lambda: call("scnattn_conv3x3_dgrad16", st, N, H, H, p, p, 1, ptr(dz2), ptr(w2), ptr(da1), None, ptr(WS), WS.numel())),
     ("conv3 wgrad 1024x256x8192 (wgrad16_w1)", 2.0 * R * p * 4 * p, 2 * (R * 4 * p + R * p) + 4 * 4 * p * p,
      lambda: call("scnattn_wgrad16_rows", st, R, p, 4 * p, ptr(dz3), ptr(a2), R, ptr(dw3), p, 0, 0, 0, 0, 0, 0, 0, ptr(WS), WS.numel(), 0)),
     ("conv2 wgrad 3x3           (wgrad16_w9)", 2.0 * R * p * 9 * p, 2 * (R * p + R * p) + 4 * 9 * p * p,

@@ -436,6 +436,47 @@ def check16():
             call("scnattn_cgemm16", stream_of(x), R, Cout, Cin, ptr(x), Cin, ptr(w), Cin, 1.0, ptr(yb), Cout, obf, ptr(WS), WS.numel(),
                  C.byref(ConvExtra(force_split=split, force_mi=mi)))
             e = rel(yb, ref + c0.double()); assert e < (4e-3 if obf else 2e-5), ("cgemm16 beta", R, Cin, Cout, split, mi, obf, e)
+    # ---- mask epilogue (EPI 2): g = (dy . W) * [fma((z - mean) * invstd, gamma, beta) > 0] rounded to bf16, and the column
+    #      sums of g and g * xhat of THOSE rounded values, for both row tiles; 1x1 d input and the stride-1 3x3 d input -----
+    for (R, K, Nn, mi) in [(8192, 1024, 256, 0), (2048, 2048, 512, 0), (32768, 512, 128, 0), (1000, 256, 64, 1), (1000, 256, 64, 2)]:
+        dy = rnd(R, K); wt = rnd(Nn, K, sc=0.1); z = rnd(R, Nn)
+        mu = (0.1 * torch.randn(Nn, generator=g)).to(dev); isd = (1 + 0.2 * torch.rand(Nn, generator=g)).to(dev)
+        ga = (1 + 0.3 * torch.randn(Nn, generator=g)).to(dev); be = (0.2 * torch.randn(Nn, generator=g)).to(dev)
+        mt = lib().scnattn_cgemm_row_tiles(R); ld = lib().scnattn_cgemm_stat_ld(R)
+        part = torch.full((2, Nn, ld), float("nan"), device=dev)
+        ex = ConvExtra(epi=2, stat_partial=part.data_ptr(), ez=z.data_ptr(), ldz=Nn, emean=mu.data_ptr(), einvstd=isd.data_ptr(),
+                       egamma=ga.data_ptr(), ebeta=be.data_ptr(), force_mi=mi)
+        gk = torch.full((R, Nn), float("nan"), device=dev, dtype=BF)
+        call("scnattn_cgemm16", stream_of(dy), R, Nn, K, ptr(dy), K, ptr(wt), K, 0.0, ptr(gk), Nn, 1, ptr(WS), WS.numel(), C.byref(ex))
+        xh = (z.float() - mu) * isd
+        mask = torch.addcmul(be, xh, ga) > 0
+        ref = (dy.double() @ wt.double().t()) * mask.double()
+        e = rel(gk, ref); assert e < 4e-3, ("cgemm16 mask", R, K, Nn, mi, e)
+        assert bool(((gk == 0) | mask).all()), "a masked element is not zero"
+        gq = gk.double()                                  # the sums are those of the stored (rounded) values
+        e1 = rel(part[0, :, :mt].double().sum(1), gq.sum(0)); e2 = rel(part[1, :, :mt].double().sum(1), (gq * xh.double()).sum(0))
+        assert e1 < 2e-5 and e2 < 2e-5, ("cgemm16 mask sums", R, K, Nn, mi, e1, e2)
+    for (N, H, W, Cc) in [(32, 16, 16, 256), (4, 9, 20, 64), (8, 32, 32, 128)]:
+        conv = torch.nn.Conv2d(Cc, Cc, 3, stride=1, padding=1, bias=False).to(dev).to(memory_format=torch.channels_last)
+        C16.refresh_weights(torch.nn.Sequential(conv))
+        R = N * H * W
+        dy = rnd(N, H, W, Cc); z = rnd(R, Cc)
+        mu = (0.1 * torch.randn(Cc, generator=g)).to(dev); isd = (1 + 0.2 * torch.rand(Cc, generator=g)).to(dev)
+        ga = (1 + 0.3 * torch.randn(Cc, generator=g)).to(dev); be = (0.2 * torch.randn(Cc, generator=g)).to(dev)
+        mt = lib().scnattn_cgemm_row_tiles(R); ld = lib().scnattn_cgemm_stat_ld(R)
+        part = torch.full((2, Cc, ld), float("nan"), device=dev)
+        ex = ConvExtra(epi=2, stat_partial=part.data_ptr(), ez=z.data_ptr(), ldz=Cc, emean=mu.data_ptr(), einvstd=isd.data_ptr(),
+                       egamma=ga.data_ptr(), ebeta=be.data_ptr())
+        gk = torch.full((R, Cc), float("nan"), device=dev, dtype=BF)
+        call("scnattn_conv3x3_dgrad16", stream_of(dy), N, H, W, Cc, Cc, 1, ptr(dy), ptr(conv._w16t), ptr(gk), C.byref(ex), ptr(WS), WS.numel())
+        wq = conv.weight.detach().to(BF).double()
+        dxr = F.conv_transpose2d(dy.double().permute(0, 3, 1, 2), wq, stride=1, padding=1).permute(0, 2, 3, 1).reshape(R, Cc)
+        xh = (z.float() - mu) * isd
+        mask = torch.addcmul(be, xh, ga) > 0
+        e = rel(gk, dxr * mask.double()); assert e < 4e-3, ("conv3 dgrad16 mask", N, H, W, Cc, e)
+        gq = gk.double()
+        e1 = rel(part[0, :, :mt].double().sum(1), gq.sum(0)); e2 = rel(part[1, :, :mt].double().sum(1), (gq * xh.double()).sum(0))
+        assert e1 < 2e-5 and e2 < 2e-5, ("conv3 dgrad16 mask sums", N, H, W, Cc, e1, e2)
     Bn, Hi, Cin, Cout = 3, 8, 64, 128
     xm = rnd(Bn, Hi, Hi, Cin); w = rnd(Cout, Cin, sc=0.1)
     xs = xm[:, ::2, ::2].reshape(-1, Cin).contiguous()
@@ -469,7 +510,7 @@ def check16():
         ref.backward(dy.double().permute(0, 3, 1, 2))
         if s == 1 or (H % 2 == 0 and W % 2 == 0):
             dx = torch.full((N * H * W, Cin), float("nan"), device=dev, dtype=BF)
-            call("scnattn_conv3x3_dgrad16", stream_of(x), N, H, W, Cin, Cout, s, ptr(dy), ptr(conv._w16t), ptr(dx), ptr(WS), WS.numel())
+            call("scnattn_conv3x3_dgrad16", stream_of(x), N, H, W, Cin, Cout, s, ptr(dy), ptr(conv._w16t), ptr(dx), None, ptr(WS), WS.numel())
             e = rel(dx, xd.grad.permute(0, 2, 3, 1).reshape(-1, Cin)); assert e < 4e-3, ("conv3 dgrad16", N, H, W, Cin, Cout, s, e)
         dwr = wd_.grad.permute(0, 2, 3, 1)                 # [Cout][3][3][Cin]
         dw = torch.full((Cout, 3, 3, Cin), float("nan"), device=dev)
@@ -553,7 +594,7 @@ def time16():
              t_us(lambda: call("scnattn_wgrad16_rows", stream_of(x), Rin, Cin, p, ptr(dz1), ptr(x), Rin, ptr(dw1), Cin, 0, 0, 0, 0, 0, 0, 0, ptr(WS), WS.numel(), 0)),
              t_us(lambda: call("scnattn_wgrad16_rows", stream_of(x), Rout, p, 4 * p, ptr(dz3), ptr(a2), Rout, ptr(dw3), p, 0, 0, 0, 0, 0, 0, 0, ptr(WS), WS.numel(), 0)),
              t_us(lambda: call("scnattn_conv3x3_fwd16", stream_of(x), N, H, H, p, p, s, ptr(a1), ptr(w2), ptr(z2), C.byref(ex), ptr(WS), WS.numel())),
-             t_us(lambda: call("scnattn_conv3x3_dgrad16", stream_of(x), N, H, H, p, p, s, ptr(dz2), ptr(w2), ptr(da1), ptr(WS), WS.numel())),
+             t_us(lambda: call("scnattn_conv3x3_dgrad16", stream_of(x), N, H, H, p, p, s, ptr(dz2), ptr(w2), ptr(da1), None, ptr(WS), WS.numel())),
              t_us(lambda: call("scnattn_wgrad16_3x3", stream_of(x), N, H, H, p, p, ptr(dz2), ptr(a1), ptr(dw2), ptr(WS), WS.numel(), 0)) if s == 1 else float("nan")]
         print("%-5s | %s" % (name, " ".join("%7.1f" % v for v in t)), flush=True)
 
