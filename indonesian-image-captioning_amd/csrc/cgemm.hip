@@ -10,8 +10,9 @@
 //   * 128x128x16 block tile, 4 waves as 2x2, each wave 2x2 MFMA 32x32 tiles (MI = 2); a 64x128x16 variant (MI = 1,
 //     each wave 1x2 tiles) for products whose 128-row tile grid cannot fill 256 CUs but whose 64-row grid can;
 //   * operands go global -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, 1 KiB per wave-instruction, hardware
-//     range checking: rows / k beyond the matrix land as zeros), 3-stage ring, ONE raw s_barrier per k-step and a
-//     counted `s_waitcnt vmcnt(N)` that leaves the next tile's loads in flight across it;
+//     range checking: rows / k beyond the matrix land as zeros), 3-slot ring + two register sets of MFMA fragments;
+//     fragment reads and LDS-DMA pieces are issued INSIDE the MFMA chain (one per gap), between two chains there is
+//     ONE counted `s_waitcnt vmcnt(N)` and ONE raw s_barrier (round 3; see the k-loop);
 //   * two LDS images, chosen per operand by which of its dimensions is contiguous in memory:
 //       KC (k contiguous, e.g. activations [R][Cin], weights [Cout][Cin]):  [row][16 k], 64-byte rows, the four
 //          16-byte granules of a row XOR-swizzled by (row>>2)&3 on the SOURCE address (the LDS-DMA destination is
@@ -21,19 +22,21 @@
 //     long as A and B agree), which is what makes the KC fragment 32 contiguous bytes;
 //   * XCD-aware tile order: the 8 XCDs own contiguous runs of row panels, n fastest, so an activation panel is
 //     fetched from HBM once per XCD and the weights stay in that XCD's L2;
-//   * optional A-operand prologue on the fragment registers: a = relu(a*scale[k] + shift[k]) (the previous layer's
-//     BatchNorm + ReLU folded to one fma, per input channel) -- the normalised map is never written to HBM;
-//     scale/shift of the current k-step travel through the LDS ring with the tile;
+//   * optional A-operand prologue: a = relu(a*scale[k] + shift[k]) (the previous layer's BatchNorm + ReLU folded to one
+//     fma, per input channel) as an in-place pass over the landed tile, in two pieces inside the MFMA chain -- the
+//     normalised map is never written to HBM; scale/shift of the k-step travel through the LDS ring with the tile;
 //   * optional per-column prologue on a MC B operand (wgrad: B = relu(bn(z)) with the channel on the column);
 //   * optional statistics epilogue: per (64-row block, column) sums of (y - s) and (y - s)^2 for the NEXT BatchNorm
 //     (s = a per-channel shift for conditioning, e.g. the running mean), fixed order, no atomics, taken straight from
 //     the accumulators before the stores are issued;
-//   * optional mask/statistics pass for dgrad (cstats_kernel<2>, also the split-K reducer): g = dx * [relu-mask
-//     recomputed from z], column sums of g and g*xhat (the BatchNorm backward reductions), g stored in place;
+//   * optional mask epilogue for d-input products (EPI 2; round 3: inside the launch): g = dx * [relu-mask recomputed
+//     from z], column sums of g and g*xhat (the BatchNorm backward reductions);  cstats_kernel<2> is the same as a second
+//     launch for the layouts the in-launch form does not cover;
 //   * C rows (and split-K slab rows) leave through a wave-private LDS transpose as 16-byte range-checked buffer stores
 //     (16 store instructions per wave instead of 64);
-//   * split-K into slabs reduced by a second launch in slab order (deterministic), for shapes whose tile grid alone
-//     cannot fill 256 CUs.
+//   * split-K into slabs, for shapes whose tile grid alone cannot fill 256 CUs; the slabs are summed in slab order
+//     (deterministic) by the workgroup that arrives last at a tile, inside the launch, epilogue included (round 3; S <= 8),
+//     or by a second launch (deeper splits, scalar stores).
 #include "common.h"
 #include "kernels.h"
 #include <map>
