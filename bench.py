@@ -546,7 +546,7 @@ def main():
                                    "note": ("one launch bracketed by two HIP event records on the launch stream, measured in "
                                             "two extra steps outside the timed region: the bracket adds the processing of "
                                             "its own two markers (~3 us); rocprofv3's duration of this kernel inside the same "
-                                            "step is 7.7 us (profiles/r02_full_step_kernel_stats_final.csv)")
+                                            "step is 7.7 us (profiles/r03_full_step_kernel_stats_fp32.csv)")
                                    },
                                "bwd_avg_step_us": round(1e3 * prof[2] / prof[3], 2) if prof[3] > 0 else None}
         if enc_ms is not None:
