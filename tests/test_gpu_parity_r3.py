@@ -62,6 +62,16 @@ def test_stem_and_finalize_on_load_kernels_vs_fp64(dev):
     mod.checkbn()
 
 
+def test_in_launch_split_k_combine_is_bit_identical_under_uneven_load(dev):
+    """csrc/cgemm.hip finishes a split product inside its launch: the workgroup that draws the last ticket of a tile sums the
+    slabs in slab order and runs the epilogue (plain, beta = 1, statistics, mask).  Against the two-launch protocol
+    (option cgemm_combine = 0) the products must be BIT-identical and the statistics partials equal to 2e-5, for both
+    publish forms (write-through slabs; plain slabs + agent release), five shapes x splits 2 / 3 / 4 / 8 x six repetitions,
+    while a second stream keeps the chip unevenly busy and the last arriver's caches warm (tools/cgemm_bench.py comb;
+    MI355X_MICROARCH.md: "test every hand-off under uneven load, consumer L1-warm, checking every word")."""
+    _tool().comb(timing=False)
+
+
 def test_stem_module_path_matches_torch_ops(dev):
     """scnattn/stem.py through EncoderCaption's trunk: the fused stem (training mode: batch statistics + running-stat
     update; eval mode: running statistics) against the same four nn modules run by torch on the CPU in fp64."""

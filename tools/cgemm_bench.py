@@ -143,7 +143,7 @@ def check():
     print("check ok, worst rel err %.2e" % worst, flush=True)
 
 
-def comb():
+def comb(timing=True):
     """In-launch split-K combine (cgemm_combine 1: write-through slabs, 2: plain slabs + agent release) against the two-launch
     protocol (0): the outputs must be BIT-identical (same slab order), also while a second stream keeps the chip unevenly
     busy and the consumer's caches warm; then the time per launch of the trunk's split products under each protocol."""
@@ -203,6 +203,9 @@ def comb():
                             print("BETA", (R, Cin, Cout), split, mode, rep, e, flush=True)
     assert nbad == 0, "in-launch combine differs from the two-launch protocol"
     print("combine: bit-identical to the two-launch protocol on every shape / split / repetition", flush=True)
+    if not timing:
+        SF.set_option("cgemm_combine", 1)
+        return
     shapes = [("l1.conv1", 64, 64, 256, 64), ("l1.conv3", 64, 64, 64, 256), ("l2.conv1", 32, 32, 512, 128),
               ("l2.conv3", 32, 32, 128, 512), ("l3.conv1", 16, 16, 1024, 256), ("l3.conv3", 16, 16, 256, 1024),
               ("l4.conv1", 8, 8, 2048, 512), ("l4.conv3", 8, 8, 512, 2048)]
