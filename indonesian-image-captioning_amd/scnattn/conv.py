@@ -22,8 +22,9 @@ d weight -- runs on the hand-written kernels of csrc/cgemm.hip / csrc/conv3.hip,
 The strided 1x1 downsample convolution gathers its input rows inside the kernel.  No library (MIOpen / rocBLAS) kernel
 runs in a block; `SCNATTN_CONV3=miopen` swaps conv2 back to MIOpen for A/B measurements only.
 
-`Bottleneck.forward` (scnattn/resnet.py) calls `bottleneck()` for fp32 CUDA inputs in training mode; everything else
-(eval mode, bf16 autocast, CPU structure tests) takes the unfused module path."""
+`Bottleneck.forward` (scnattn/resnet.py) calls `bottleneck()` for fp32 CUDA inputs in training mode and
+scnattn/conv16.py's mixed-precision twin for bf16 ones; everything else (eval mode, CPU structure tests) takes the
+unfused module path."""
 import ctypes as C
 import os
 
